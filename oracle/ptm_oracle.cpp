@@ -1,0 +1,847 @@
+/*
+ * ptm_oracle.cpp — CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A scalar IEEE-754 f32 restatement of the reference's WGSL integrator, one function per WGSL
+ * function, each citing the reference file:line it follows (paths relative to the reference repo).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The product (webgpu-path-tracer_amd/csrc) never includes, links or calls anything in oracle/.
+ *
+ * PARITY STATUS: the reference has no tests, no golden images and no runnable CPU/WGSL path in this
+ * environment — the device algorithm here is "parity unpinned" by the reference's
+ * own fixtures.  It is pinned by (a) analytic known-answer tests in tests/test_oracle_kat.py,
+ * (b) PCG vectors cross-checked with an independent numpy evaluation, (c) brute-force-vs-BVH
+ * equivalence.  The host-buffer layouts it consumes ARE pinned by goldens captured from the
+ * reference's own JavaScript (tests/golden/, oracle/capture/).
+ *
+ * Evaluation rules: every expression is transcribed with the WGSL source's
+ * association, no algebraic tidying; compile with -ffp-contract=off, no fast-math.  Builtins with
+ * implementation-defined accuracy (sin cos acos log pow) come from include/ptmi_math.h, which the
+ * device code shares so that both sides agree bit for bit; +,-,*,/,sqrt are IEEE correctly rounded.
+ */
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+
+#include "../include/ptmi_math.h"
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+// ---- shaders/header.wgsl:1-13 constants (abstract-float consts folded in f64, rounded once) ----
+constexpr float PI_F = 3.14159265358979323846;        // header.wgsl:1
+constexpr float TWO_PI_F = 2.0 * 3.14159265358979323846;  // `2 * PI` const-expression sites
+constexpr float MIN_FLOAT = 0.0001;                   // header.wgsl:2
+constexpr float MAX_FLOAT = 999999999.999;            // header.wgsl:3  -> 1.0e9f
+constexpr float MAX_FLOAT_P1 = 999999999.999 + 1.0;   // `MAX_FLOAT + 1` -> also 1.0e9f (ulp = 64)
+constexpr float LAMBERTIAN = 0, MIRROR = 1, GLASS = 2, ISOTROPIC = 3;  // header.wgsl:4-7
+constexpr float RAY_TMIN = 0.000001;                  // header.wgsl:37
+
+struct vec3 {
+  float x, y, z;
+};
+struct vec4 {
+  float x, y, z, w;
+};
+inline vec3 V(float x, float y, float z) { return vec3{x, y, z}; }
+inline vec3 operator+(vec3 a, vec3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline vec3 operator-(vec3 a, vec3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline vec3 operator*(vec3 a, vec3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+inline vec3 operator*(vec3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+inline vec3 operator*(float s, vec3 a) { return V(s * a.x, s * a.y, s * a.z); }
+inline vec3 operator/(vec3 a, float s) { return V(a.x / s, a.y / s, a.z / s); }
+inline vec3 operator-(vec3 a) { return V(-a.x, -a.y, -a.z); }
+// WGSL dot/cross/length/normalize: dot = (x*x' + y*y') + z*z' (§8a-W "summation order")
+inline float dot(vec3 a, vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline float dot4(vec4 a, vec4 b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }
+inline vec3 cross(vec3 a, vec3 b) {
+  return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+inline float length(vec3 a) { return ptm_sqrt(dot(a, a)); }
+inline vec3 normalize(vec3 a) { return a / length(a); }
+inline vec3 mix(vec3 a, vec3 b, float t) { return a * (1.0f - t) + b * t; }  // a*(1-t)+b*t, Q12
+inline vec3 reflect(vec3 e1, vec3 e2) { return e1 - (2.0f * dot(e2, e1)) * e2; }
+inline vec3 refract(vec3 e1, vec3 e2, float e3) {
+  float d = dot(e2, e1);
+  float k = 1.0f - e3 * e3 * (1.0f - d * d);
+  if (k < 0.0f) return V(0, 0, 0);
+  return e3 * e1 - (e3 * d + ptm_sqrt(k)) * e2;
+}
+inline float idx(vec3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+// column-major mat4 * vec4: ((c0*x + c1*y) + c2*z) + c3*w
+inline vec4 mat_mul(const float* m, vec4 v) {
+  vec4 r;
+  r.x = ((m[0] * v.x + m[4] * v.y) + m[8] * v.z) + m[12] * v.w;
+  r.y = ((m[1] * v.x + m[5] * v.y) + m[9] * v.z) + m[13] * v.w;
+  r.z = ((m[2] * v.x + m[6] * v.y) + m[10] * v.z) + m[14] * v.w;
+  r.w = ((m[3] * v.x + m[7] * v.y) + m[11] * v.z) + m[15] * v.w;
+  return r;
+}
+// transpose(m) * vec4: column c of the transpose is row c of m
+inline vec4 mat_mul_transposed(const float* m, vec4 v) {
+  vec4 r;
+  r.x = ((m[0] * v.x + m[1] * v.y) + m[2] * v.z) + m[3] * v.w;
+  r.y = ((m[4] * v.x + m[5] * v.y) + m[6] * v.z) + m[7] * v.w;
+  r.z = ((m[8] * v.x + m[9] * v.y) + m[10] * v.z) + m[11] * v.w;
+  r.w = ((m[12] * v.x + m[13] * v.y) + m[14] * v.z) + m[15] * v.w;
+  return r;
+}
+
+struct Ray {
+  vec3 origin, dir;
+};
+inline vec3 at(Ray r, float t) { return r.origin + t * r.dir; }  // common.wgsl:1-3
+
+// shaders/header.wgsl:53-61
+struct Material {
+  vec3 color;
+  vec3 specularColor;
+  vec3 emissionColor;
+  float specularStrength, roughness, eta, material_type;
+  float raw[16];
+};
+struct Quad {  // header.wgsl:76-86
+  vec3 Q, u, v, normal, w;
+  float local_id, global_id, D, material_id;
+};
+struct HitRecord {  // header.wgsl:119-125
+  vec3 p;
+  float t;
+  vec3 normal;
+  bool front_face;
+  Material material;
+};
+struct ScatterRecord {  // header.wgsl:127-131
+  float pdf;
+  bool skip_pdf;
+  Ray skip_pdf_ray;
+};
+
+}  // namespace
+
+extern "C" {
+
+struct ptmo_scene {
+  const float* spheres;     int32_t n_spheres;     //  8 f32 each
+  const float* quads;       int32_t n_quads;       // 20 f32 each
+  const float* triangles;   int32_t n_triangles;   // 24 f32 each
+  const int32_t* meshes;    int32_t n_meshes;      //  4 i32 each
+  const float* transforms;  int32_t n_transforms;  // 32 f32 each
+  const float* materials;   int32_t n_materials;   // 16 f32 each
+  const float* bvh;         int32_t n_nodes;       // 12 f32 each
+};
+struct ptmo_params {
+  int32_t num_samples;          // NUM_SAMPLES  header.wgsl:9
+  int32_t max_bounces;          // MAX_BOUNCES  header.wgsl:10
+  int32_t stratify;             // STRATIFY     header.wgsl:11
+  int32_t importance_sampling;  // IMPORTANCE_SAMPLING header.wgsl:12
+  int32_t stack_size;           // STACK_SIZE   header.wgsl:13
+  float background[3];          // traceRay.wgsl:8
+  float fov_factor;             // main.wgsl:7, folded in f64 by the caller
+};
+struct ptmo_stats {
+  uint64_t rays;          // hitScene invocations
+  uint64_t node_visits;   // hit_aabb calls
+  uint64_t tri_tests;     // hit_triangle calls
+  uint64_t sphere_tests;  // hit_sphere + hit_volume calls
+  uint64_t quad_tests;    // hit_quad calls
+  uint64_t mat_fetches;   // `hitRec.material = materials[..]` executions
+  uint64_t paths;         // ray_color invocations
+};
+struct ptmo_hit {
+  int32_t hit;
+  float t;
+  float p[3];
+  float normal[3];
+  int32_t front_face;
+  float material[16];
+};
+}
+
+namespace {
+
+// All `var<private>` state of one invocation (header.wgsl:25-39, scatterRay.wgsl:1,
+// importanceSampling.wgsl:56-58, shootRay.wgsl:51-52) plus the bound buffers.
+struct Thread {
+  const ptmo_scene* s;
+  const ptmo_params* prm;
+  const float* uniforms;  // 20 f32: W, H, frameNum, resetBuffer, viewMatrix[16]
+  ptmo_stats st;
+
+  uint32_t randState = 0;
+  vec3 pixelCoords;
+  HitRecord hitRec;
+  ScatterRecord scatterRec;
+  Quad lights;
+  float ray_tmin = RAY_TMIN;
+  int32_t stack[64];  // STACK_SIZE <= 64 enforced by the entry points
+  float doSpecular = 0;
+  vec3 unit_w, u, v;
+  float fovFactor;
+  vec3 cam_origin;
+
+  Thread(const ptmo_scene* s_, const ptmo_params* p_, const float* un) : s(s_), prm(p_), uniforms(un) {
+    memset(&st, 0, sizeof st);
+    memset(&hitRec, 0, sizeof hitRec);
+    memset(&scatterRec, 0, sizeof scatterRec);
+    memset(&lights, 0, sizeof lights);
+    pixelCoords = unit_w = u = v = cam_origin = V(0, 0, 0);
+    memset(stack, 0, sizeof stack);
+    fovFactor = p_->fov_factor;
+  }
+
+  Material load_material(int i) {
+    const float* m = s->materials + 16 * (size_t)i;
+    Material r;
+    r.color = V(m[0], m[1], m[2]);
+    r.specularColor = V(m[4], m[5], m[6]);
+    r.emissionColor = V(m[8], m[9], m[10]);
+    r.specularStrength = m[11];
+    r.roughness = m[12];
+    r.eta = m[13];
+    r.material_type = m[14];
+    memcpy(r.raw, m, 64);
+    return r;
+  }
+  Quad load_quad(int i) {
+    const float* q = s->quads + 20 * (size_t)i;
+    Quad r;
+    r.Q = V(q[0], q[1], q[2]);
+    r.u = V(q[4], q[5], q[6]);
+    r.local_id = q[7];
+    r.v = V(q[8], q[9], q[10]);
+    r.global_id = q[11];
+    r.normal = V(q[12], q[13], q[14]);
+    r.D = q[15];
+    r.w = V(q[16], q[17], q[18]);
+    r.material_id = q[19];
+    return r;
+  }
+
+  // shaders/common.wgsl:7-12
+  float rand2D() {
+    randState = randState * 747796405u + 2891336453u;
+    uint32_t word = ((randState >> ((randState >> 28u) + 4u)) ^ randState) * 277803737u;
+    return (float)((word >> 22u) ^ word) / 4294967296.0f;  // f32(4294967295) == 2^32
+  }
+
+  // shaders/common.wgsl:29-73
+  bool hit_sphere(const float* sp, float tmin, float tmax, Ray ray) {
+    st.sphere_tests++;
+    vec3 center = V(sp[0], sp[1], sp[2]);
+    float r = sp[3];
+    vec3 oc = ray.origin - center;
+    float a = dot(ray.dir, ray.dir);
+    float half_b = dot(ray.dir, oc);
+    float c = dot(oc, oc) - r * r;
+    float discriminant = half_b * half_b - a * c;
+    if (discriminant < 0) return false;
+    float sqrtd = ptm_sqrt(discriminant);
+    float root = (-half_b - sqrtd) / a;
+    if (root <= tmin || root >= tmax) {
+      root = (-half_b + sqrtd) / a;
+      if (root <= tmin || root >= tmax) return false;
+    }
+    hitRec.t = root;
+    hitRec.p = at(ray, root);
+    hitRec.normal = normalize((hitRec.p - center) / r);
+    hitRec.front_face = dot(ray.dir, hitRec.normal) < 0;
+    if (hitRec.front_face == false) hitRec.normal = -hitRec.normal;
+    hitRec.material = load_material((int)sp[6]);
+    st.mat_fetches++;
+    return true;
+  }
+
+  // shaders/common.wgsl:75-100
+  float hit_sphere_local(const float* sp, float tmin, float tmax, Ray ray) {
+    vec3 center = V(sp[0], sp[1], sp[2]);
+    float r = sp[3];
+    vec3 oc = ray.origin - center;
+    float a = dot(ray.dir, ray.dir);
+    float half_b = dot(ray.dir, oc);
+    float c = dot(oc, oc) - r * r;
+    float discriminant = half_b * half_b - a * c;
+    if (discriminant < 0) return MAX_FLOAT_P1;
+    float sqrtd = ptm_sqrt(discriminant);
+    float root = (-half_b - sqrtd) / a;
+    if (root <= tmin || root >= tmax) {
+      root = (-half_b + sqrtd) / a;
+      if (root <= tmin || root >= tmax) return MAX_FLOAT_P1;
+    }
+    return root;
+  }
+
+  // shaders/common.wgsl:102-146
+  bool hit_volume(const float* sp, float tmin, float tmax, Ray ray) {
+    st.sphere_tests++;
+    float rec1 = hit_sphere_local(sp, -MAX_FLOAT, MAX_FLOAT, ray);
+    if (rec1 == MAX_FLOAT_P1) return false;
+    float rec2 = hit_sphere_local(sp, rec1 + 0.0001f, MAX_FLOAT, ray);
+    if (rec2 == MAX_FLOAT_P1) return false;
+    if (rec1 < tmin) rec1 = tmin;
+    if (rec2 > tmax) rec2 = tmax;
+    if (rec1 >= rec2) return false;
+    if (rec1 < 0) rec1 = 0;
+    hitRec.material = load_material((int)sp[6]);  // :130 — before the final accept/reject (Q3)
+    st.mat_fetches++;
+    float ray_length = length(ray.dir);
+    float dist_inside = (rec2 - rec1) * ray_length;
+    float hit_dist = hitRec.material.roughness * ptm_log(rand2D());
+    if (hit_dist > dist_inside) return false;
+    hitRec.t = rec1 + (hit_dist / ray_length);
+    hitRec.p = at(ray, hitRec.t);
+    hitRec.normal = normalize(hitRec.p - V(sp[0], sp[1], sp[2]));
+    hitRec.front_face = true;
+    return true;
+  }
+
+  // shaders/common.wgsl:148-187
+  bool hit_quad(const Quad& quad, float tmin, float tmax, Ray ray) {
+    st.quad_tests++;
+    if (dot(ray.dir, quad.normal) > 0) return false;
+    float denom = dot(quad.normal, ray.dir);
+    if (ptm_abs(denom) < 1e-8f) return false;
+    float t = (quad.D - dot(quad.normal, ray.origin)) / denom;
+    if (t <= tmin || t >= tmax) return false;
+    vec3 intersection = at(ray, t);
+    vec3 planar_hitpt_vector = intersection - quad.Q;
+    float alpha = dot(quad.w, cross(planar_hitpt_vector, quad.v));
+    float beta = dot(quad.w, cross(quad.u, planar_hitpt_vector));
+    if (alpha < 0 || 1 < alpha || beta < 0 || 1 < beta) return false;
+    hitRec.t = t;
+    hitRec.p = intersection;
+    hitRec.normal = normalize(quad.normal);
+    hitRec.front_face = dot(ray.dir, hitRec.normal) < 0;
+    if (hitRec.front_face == false) hitRec.normal = -hitRec.normal;
+    hitRec.material = load_material((int)quad.material_id);
+    st.mat_fetches++;
+    return true;
+  }
+
+  // shaders/common.wgsl:191-242
+  bool hit_triangle(const float* tri, float tmin, float tmax, Ray incidentRay) {
+    st.tri_tests++;
+    const int32_t* mesh = s->meshes + 4 * (size_t)(int)tri[23];
+    const float* modelT = s->transforms + 32 * (size_t)mesh[2];
+    const float* invModelMatrix = modelT + 16;
+    vec4 o4 = mat_mul(invModelMatrix, vec4{incidentRay.origin.x, incidentRay.origin.y, incidentRay.origin.z, 1.0f});
+    vec4 d4 = mat_mul(invModelMatrix, vec4{incidentRay.dir.x, incidentRay.dir.y, incidentRay.dir.z, 0.0f});
+    Ray ray{V(o4.x, o4.y, o4.z), V(d4.x, d4.y, d4.z)};
+    vec3 A = V(tri[0], tri[1], tri[2]), B = V(tri[4], tri[5], tri[6]), C = V(tri[8], tri[9], tri[10]);
+    vec3 AB = B - A;
+    vec3 AC = C - A;
+    vec3 normal = cross(AB, AC);
+    float determinant = -dot(ray.dir, normal);
+    if (ptm_abs(determinant) < tmin) return false;
+    vec3 ao = ray.origin - A;
+    vec3 dao = cross(ao, ray.dir);
+    float invDet = 1.0f / determinant;
+    float dst = dot(ao, normal) * invDet;
+    float uu = dot(AC, dao) * invDet;
+    float vv = -dot(AB, dao) * invDet;
+    float ww = 1.0f - uu - vv;
+    if (dst < tmin || dst > tmax || uu < tmin || vv < tmin || ww < tmin) return false;
+    hitRec.t = dst;
+    hitRec.p = at(incidentRay, dst);
+    vec3 nA = V(tri[12], tri[13], tri[14]), nB = V(tri[16], tri[17], tri[18]), nC = V(tri[20], tri[21], tri[22]);
+    hitRec.normal = nA * ww + nB * uu + nC * vv;
+    vec4 n4 = mat_mul_transposed(invModelMatrix, vec4{hitRec.normal.x, hitRec.normal.y, hitRec.normal.z, 0.0f});
+    hitRec.normal = normalize(V(n4.x, n4.y, n4.z));
+    hitRec.front_face = dot(incidentRay.dir, hitRec.normal) < 0;
+    if (hitRec.front_face == false) hitRec.normal = -hitRec.normal;
+    hitRec.material = load_material(mesh[3]);
+    st.mat_fetches++;
+    return true;
+  }
+
+  // shaders/common.wgsl:245-256
+  bool hit_aabb(const float* box, float tmin, float tmax, Ray ray, vec3 invDir) {
+    st.node_visits++;
+    vec3 bmin = V(box[0], box[1], box[2]), bmax = V(box[4], box[5], box[6]);
+    vec3 t0s = (bmin - ray.origin) * invDir;
+    vec3 t1s = (bmax - ray.origin) * invDir;
+    vec3 tsmaller = V(ptm_min(t0s.x, t1s.x), ptm_min(t0s.y, t1s.y), ptm_min(t0s.z, t1s.z));
+    vec3 tbigger = V(ptm_max(t0s.x, t1s.x), ptm_max(t0s.y, t1s.y), ptm_max(t0s.z, t1s.z));
+    float t_min = ptm_max(tmin, ptm_max(tsmaller.x, ptm_max(tsmaller.y, tsmaller.z)));
+    float t_max = ptm_min(tmax, ptm_min(tbigger.x, ptm_min(tbigger.y, tbigger.z)));
+    return t_max > t_min;
+  }
+
+  // shaders/hitRay.wgsl:1-113
+  bool hitScene(Ray ray) {
+    st.rays++;
+    float closest_so_far = MAX_FLOAT;
+    bool hit_anything = false;
+
+    for (int i = 0; i < s->n_spheres; i++) {
+      const float* sp = s->spheres + 8 * (size_t)i;
+      float medium = s->materials[16 * (size_t)(int)sp[6] + 14];
+      if (medium < ISOTROPIC) {
+        if (hit_sphere(sp, ray_tmin, closest_so_far, ray)) {
+          hit_anything = true;
+          closest_so_far = hitRec.t;
+        }
+      } else {
+        if (hit_volume(sp, ray_tmin, closest_so_far, ray)) {
+          hit_anything = true;
+          closest_so_far = hitRec.t;
+        }
+      }
+    }
+    for (int i = 0; i < s->n_quads; i++) {
+      if (hit_quad(load_quad(i), ray_tmin, closest_so_far, ray)) {
+        hit_anything = true;
+        closest_so_far = hitRec.t;
+      }
+    }
+
+    // An empty bvh binding cannot exist in WebGPU; the build defines it as
+    // "no triangle geometry": the traversal is skipped.
+    if (s->n_nodes <= 0) return hit_anything;
+
+    const int leafNode = 2;
+    vec3 invDir = V(1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z);
+    int toVisitOffset = 0;
+    int curNodeIdx = 0;
+    const int STACK_SIZE = prm->stack_size;
+    while (true) {
+      const float* node = s->bvh + 12 * (size_t)curNodeIdx;
+      if (hit_aabb(node, ray_tmin, closest_so_far, ray, invDir)) {
+        if ((int)node[7] == leafNode) {
+          int startPrim = (int)node[8];
+          int countPrim = (int)node[9];
+          for (int j = 0; j < countPrim; j++) {
+            if (hit_triangle(s->triangles + 24 * (size_t)(startPrim + j), ray_tmin, closest_so_far, ray)) {
+              hit_anything = true;
+              closest_so_far = hitRec.t;
+            }
+          }
+          if (toVisitOffset == 0) break;
+          toVisitOffset--;
+          curNodeIdx = stack[toVisitOffset];
+        } else {
+          if (idx(ray.dir, (int)node[11]) < 0) {
+            stack[toVisitOffset] = curNodeIdx + 1;
+            toVisitOffset++;
+            curNodeIdx = (int)node[3];
+          } else {
+            stack[toVisitOffset] = (int)node[3];
+            toVisitOffset++;
+            curNodeIdx++;
+          }
+        }
+      } else {
+        if (toVisitOffset == 0) break;
+        toVisitOffset--;
+        curNodeIdx = stack[toVisitOffset];
+      }
+      if (toVisitOffset >= STACK_SIZE) break;  // hitRay.wgsl:106-109 (Q7)
+    }
+    return hit_anything;
+  }
+
+  // shaders/importanceSampling.wgsl:1-5
+  float reflectance(float cosine, float ref_idx) {
+    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    r0 = r0 * r0;
+    return r0 + (1.0f - r0) * ptm_pow((1.0f - cosine), 5.0f);
+  }
+  // shaders/importanceSampling.wgsl:7-16
+  vec3 uniform_random_in_unit_sphere() {
+    float phi = rand2D() * 2.0f * PI_F;
+    float theta = ptm_acos(2.0f * rand2D() - 1.0f);
+    float x = ptm_sin(theta) * ptm_cos(phi);
+    float y = ptm_sin(theta) * ptm_sin(phi);
+    float z = ptm_cos(theta);
+    return normalize(V(x, y, z));
+  }
+  // shaders/importanceSampling.wgsl:35-45
+  vec3 cosine_sampling_wrt_Z() {
+    float r1 = rand2D();
+    float r2 = rand2D();
+    float phi = TWO_PI_F * r1;
+    float x = ptm_cos(phi) * ptm_sqrt(r2);
+    float y = ptm_sin(phi) * ptm_sqrt(r2);
+    float z = ptm_sqrt(1.0f - r2);
+    return V(x, y, z);
+  }
+  // shaders/importanceSampling.wgsl:60-67
+  void onb_build_from_w(vec3 w) {
+    unit_w = normalize(w);
+    vec3 a = (ptm_abs(unit_w.x) > 0.9f) ? V(0, 1, 0) : V(1, 0, 0);
+    v = normalize(cross(unit_w, a));
+    u = cross(unit_w, v);
+  }
+  // shaders/importanceSampling.wgsl:69-71
+  vec3 onb_get_local(vec3 a) { return u * a.x + v * a.y + unit_w * a.z; }
+  // shaders/importanceSampling.wgsl:73-76
+  float onb_lambertian_scattering_pdf(Ray scattered) {
+    float cosine_theta = dot(normalize(scattered.dir), unit_w);
+    return ptm_max(0.0f, cosine_theta / PI_F);
+  }
+  // shaders/importanceSampling.wgsl:78-81
+  Ray get_random_on_quad(const Quad& q, vec3 origin) {
+    float r1 = rand2D();  // left-to-right evaluation: u draw first
+    vec3 pu = r1 * q.u;
+    float r2 = rand2D();
+    vec3 pv = r2 * q.v;
+    vec3 p = q.Q + pu + pv;
+    return Ray{origin, normalize(p - origin)};
+  }
+  // shaders/importanceSampling.wgsl:88-125
+  float light_pdf(Ray ray, const Quad& quad) {
+    if (dot(ray.dir, quad.normal) > 0) return MIN_FLOAT;
+    float denom = dot(quad.normal, ray.dir);
+    if (ptm_abs(denom) < 1e-8f) return MIN_FLOAT;
+    float t = (quad.D - dot(quad.normal, ray.origin)) / denom;
+    if (t <= 0.001f || t >= MAX_FLOAT) return MIN_FLOAT;
+    vec3 intersection = at(ray, t);
+    vec3 planar_hitpt_vector = intersection - quad.Q;
+    float alpha = dot(quad.w, cross(planar_hitpt_vector, quad.v));
+    float beta = dot(quad.w, cross(quad.u, planar_hitpt_vector));
+    if (alpha < 0 || 1 < alpha || beta < 0 || 1 < beta) return MIN_FLOAT;
+    vec3 hitNormal = quad.normal;
+    bool front_face = dot(ray.dir, quad.normal) < 0;
+    if (front_face == false) hitNormal = -hitNormal;
+    float distance_squared = t * t * length(ray.dir) * length(ray.dir);
+    float cosine = ptm_abs(dot(ray.dir, hitNormal) / length(ray.dir));
+    return (distance_squared / (cosine * length(cross(lights.u, lights.v))));  // global `lights` (:124)
+  }
+
+  // shaders/scatterRay.wgsl:2-95
+  Ray material_scatter(Ray ray_in) {
+    Ray scattered{V(0, 0, 0), V(0, 0, 0)};
+    doSpecular = 0;
+    const Material& m = hitRec.material;
+    if (m.material_type == LAMBERTIAN) {
+      onb_build_from_w(hitRec.normal);
+      vec3 diffuse_dir = cosine_sampling_wrt_Z();
+      diffuse_dir = normalize(onb_get_local(diffuse_dir));
+      scattered = Ray{hitRec.p, diffuse_dir};
+      doSpecular = (rand2D() < m.specularStrength) ? 1.0f : 0.0f;
+      vec3 specular_dir = reflect(ray_in.dir, hitRec.normal);
+      specular_dir = normalize(mix(specular_dir, diffuse_dir, m.roughness));
+      scattered = Ray{hitRec.p, normalize(mix(diffuse_dir, specular_dir, doSpecular))};
+      scatterRec.skip_pdf = false;
+      if (doSpecular == 1.0f) {
+        scatterRec.skip_pdf = true;
+        scatterRec.skip_pdf_ray = scattered;
+      }
+    } else if (m.material_type == MIRROR) {
+      vec3 reflected = reflect(ray_in.dir, hitRec.normal);
+      scattered = Ray{hitRec.p, normalize(reflected + m.roughness * uniform_random_in_unit_sphere())};
+      scatterRec.skip_pdf = true;
+      scatterRec.skip_pdf_ray = scattered;
+    } else if (m.material_type == GLASS) {
+      float ir = m.eta;
+      if (hitRec.front_face == true) ir = (1.0f / ir);
+      vec3 unit_direction = normalize(ray_in.dir);
+      float cos_theta = ptm_min(dot(-unit_direction, hitRec.normal), 1.0f);
+      float sin_theta = ptm_sqrt(1.0f - cos_theta * cos_theta);
+      vec3 direction = V(0, 0, 0);
+      if (ir * sin_theta > 1.0f || reflectance(cos_theta, ir) > rand2D()) {
+        direction = reflect(unit_direction, hitRec.normal);
+      } else {
+        direction = refract(unit_direction, hitRec.normal, ir);
+      }
+      // near_zero() is always false (common.wgsl:25-27)
+      scattered = Ray{hitRec.p, normalize(direction)};
+      scatterRec.skip_pdf = true;
+      scatterRec.skip_pdf_ray = scattered;
+    } else if (m.material_type == ISOTROPIC) {
+      float g = m.specularStrength;
+      float cos_hg = (1.0f + g * g - ptm_pow(((1.0f - g * g) / (1.0f - g + 2.0f * g * rand2D())), 2.0f)) / (2.0f * g);
+      float sin_hg = ptm_sqrt(1.0f - cos_hg * cos_hg);
+      float phi = TWO_PI_F * rand2D();
+      vec3 hg_dir = V(sin_hg * ptm_cos(phi), sin_hg * ptm_sin(phi), cos_hg);
+      onb_build_from_w(ray_in.dir);
+      scattered = Ray{hitRec.p, normalize(onb_get_local(hg_dir))};
+      scatterRec.skip_pdf = true;
+      scatterRec.skip_pdf_ray = scattered;
+    }
+    return scattered;
+  }
+
+  // shaders/traceRay.wgsl:3-83
+  vec3 ray_color(Ray incidentRay) {
+    st.paths++;
+    Ray currRay = incidentRay;
+    vec3 acc_radiance = V(0, 0, 0);
+    vec3 throughput = V(1, 1, 1);
+    vec3 background_color = V(prm->background[0], prm->background[1], prm->background[2]);
+    for (int i = 0; i < prm->max_bounces; i++) {
+      if (hitScene(currRay) == false) {
+        acc_radiance = acc_radiance + (background_color * throughput);
+        break;
+      }
+      vec3 emissionColor = hitRec.material.emissionColor;
+      if (!hitRec.front_face) emissionColor = V(0, 0, 0);
+
+      if (prm->importance_sampling) {
+        Ray scatterred_surface = material_scatter(currRay);
+        if (scatterRec.skip_pdf) {
+          acc_radiance = acc_radiance + emissionColor * throughput;
+          throughput = throughput * mix(hitRec.material.color, hitRec.material.specularColor, doSpecular);
+          currRay = scatterRec.skip_pdf_ray;
+          continue;
+        }
+        Ray scattered_light = get_random_on_quad(lights, hitRec.p);
+        Ray scattered = scattered_light;
+        float rnd = rand2D();
+        if (rnd > 0.2f) scattered = scatterred_surface;
+        float lambertian_pdf = onb_lambertian_scattering_pdf(scattered);
+        float lpdf = light_pdf(scattered, lights);
+        float pdf = 0.2f * lpdf + 0.8f * lambertian_pdf;
+        if (pdf <= 0.00001f) return emissionColor * throughput;  // drops acc (Q8)
+        acc_radiance = acc_radiance + emissionColor * throughput;
+        throughput = throughput * ((lambertian_pdf * mix(hitRec.material.color, hitRec.material.specularColor, doSpecular)) / pdf);
+        currRay = scattered;
+      } else {
+        Ray scattered = material_scatter(currRay);
+        acc_radiance = acc_radiance + emissionColor * throughput;
+        throughput = throughput * mix(hitRec.material.color, hitRec.material.specularColor, doSpecular);
+        currRay = scattered;
+      }
+      if (i > 2) {
+        float p = ptm_max(throughput.x, ptm_max(throughput.y, throughput.z));
+        if (rand2D() > p) break;
+        throughput = throughput * (1.0f / p);
+      }
+    }
+    return acc_radiance;
+  }
+
+  // shaders/shootRay.wgsl:54-60
+  Ray getCameraRay(float s_, float t_) {
+    vec4 d = mat_mul(uniforms + 4, vec4{s_, t_, -fovFactor, 0.0f});
+    float len = ptm_sqrt(dot4(d, d));  // normalize() of the vec4, then .xyz
+    return Ray{cam_origin, V(d.x / len, d.y / len, d.z / len)};
+  }
+
+  // shaders/shootRay.wgsl:5-49
+  vec3 pathTrace() {
+    vec3 pixColor = V(0, 0, 0);
+    const float W = uniforms[0], H = uniforms[1];
+    if (prm->stratify) {
+      const float sqrt_spp = (float)std::sqrt((double)prm->num_samples);
+      const float recip_sqrt_spp = 1.0f / (float)(int)sqrt_spp;
+      float numSamples = 0.0f;
+      for (float i = 0.0f; i < sqrt_spp; i += 1.0f) {
+        for (float j = 0.0f; j < sqrt_spp; j += 1.0f) {
+          float a = (W / H) * (2.0f * ((pixelCoords.x - 0.5f + (recip_sqrt_spp * (i + rand2D()))) / W) - 1.0f);
+          float b = -1.0f * (2.0f * ((pixelCoords.y - 0.5f + (recip_sqrt_spp * (j + rand2D()))) / H) - 1.0f);
+          Ray ray = getCameraRay(a, b);
+          pixColor = pixColor + ray_color(ray);
+          numSamples += 1.0f;
+        }
+      }
+      pixColor = pixColor / numSamples;
+    } else {
+      for (int i = 0; i < prm->num_samples; i += 1) {
+        float a = (W / H) * (2.0f * ((pixelCoords.x - 0.5f + rand2D()) / W) - 1.0f);
+        float b = -1.0f * (2.0f * ((pixelCoords.y - 0.5f + rand2D()) / H) - 1.0f);
+        Ray ray = getCameraRay(a, b);
+        pixColor = pixColor + ray_color(ray);
+      }
+      pixColor = pixColor / (float)prm->num_samples;
+    }
+    return pixColor;
+  }
+
+  // shaders/common.wgsl:258-269
+  void get_lights() {
+    for (int i = 0; i < s->n_quads; i++) {
+      const float* q = s->quads + 20 * (size_t)i;
+      float ex = s->materials[16 * (size_t)(int)q[19] + 8];
+      if (ex > 0.0f) {
+        lights = load_quad(i);
+        break;
+      }
+    }
+  }
+
+  // shaders/main.wgsl:1-28 — one invocation
+  void computeFrameBuffer(uint32_t pixelIndex, float* framebuffer) {
+    const float W = uniforms[0];
+    float fidx = (float)pixelIndex;
+    float q = fidx / W;
+    pixelCoords = V(fidx - W * std::trunc(q), q, 1.0f);  // f32 % = x - y*trunc(x/y); y not floored (Q1)
+    vec4 co = mat_mul(uniforms + 4, vec4{0, 0, 0, 1});
+    cam_origin = V(co.x, co.y, co.z);
+    randState = pixelIndex + (uint32_t)uniforms[2] * 719393u;
+    get_lights();
+    vec3 pathTracedColor = pathTrace();
+    vec3 fragColor = pathTracedColor;
+    float* fb = framebuffer + 4 * (size_t)pixelIndex;
+    if (uniforms[3] == 0) fragColor = V(fb[0], fb[1], fb[2]) + pathTracedColor;
+    fb[0] = fragColor.x;
+    fb[1] = fragColor.y;
+    fb[2] = fragColor.z;
+    fb[3] = 1.0f;
+  }
+};
+
+inline void add_stats(ptmo_stats* a, const ptmo_stats& b) {
+  a->rays += b.rays;
+  a->node_visits += b.node_visits;
+  a->tri_tests += b.tri_tests;
+  a->sphere_tests += b.sphere_tests;
+  a->quad_tests += b.quad_tests;
+  a->mat_fetches += b.mat_fetches;
+  a->paths += b.paths;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* Render frames [first_frame, first_frame + n_frames) into `framebuffer` (W*H*4 f32, read-modify-
+ * write exactly as main.wgsl:22-27).  uniforms20 supplies W, H, (frameNum ignored), resetBuffer for
+ * the FIRST frame only (later frames accumulate), viewMatrix.  Pixels are restricted to
+ * [px_begin, px_end) and to the tiles {p : (p / shard_tile) % shard_world == shard_rank}. */
+int ptmo_render(const ptmo_scene* scene, const ptmo_params* prm, const float* uniforms20, uint32_t first_frame,
+                uint32_t n_frames, float* framebuffer, ptmo_stats* stats_out, int n_threads, int shard_rank,
+                int shard_world, int shard_tile, int64_t px_begin, int64_t px_end) {
+  if (!scene || !prm || !uniforms20 || !framebuffer) return -1;
+  const int W = (int)uniforms20[0], H = (int)uniforms20[1];
+  if (W <= 0 || H <= 0 || prm->stack_size <= 0 || prm->stack_size > 64) return -1;
+  const int64_t npix = (int64_t)W * H;
+  if (px_begin < 0) px_begin = 0;
+  if (px_end < 0 || px_end > npix) px_end = npix;
+  if (shard_world <= 0) shard_world = 1;
+  if (shard_tile <= 0) shard_tile = 64;
+  ptmo_stats total;
+  memset(&total, 0, sizeof total);
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+  for (uint32_t f = 0; f < n_frames; f++) {
+    float un[20];
+    memcpy(un, uniforms20, sizeof un);
+    un[2] = (float)(first_frame + f);
+    if (f > 0) un[3] = 0.0f;
+#pragma omp parallel
+    {
+      Thread th(scene, prm, un);
+#pragma omp for schedule(dynamic, 256)
+      for (int64_t p = px_begin; p < px_end; p++) {
+        if (((p / shard_tile) % shard_world) != shard_rank) continue;
+        // private state is per invocation in WGSL: fresh zero-initialised each pixel
+        Thread t(scene, prm, un);
+        t.computeFrameBuffer((uint32_t)p, framebuffer);
+        add_stats(&th.st, t.st);
+      }
+#pragma omp critical
+      add_stats(&total, th.st);
+    }
+  }
+  if (stats_out) *stats_out = total;
+  return 0;
+}
+
+/* hitScene on caller-supplied rays (6 f32 each: origin, dir) with per-ray RNG state (consumed only
+ * by hit_volume).  Each ray starts from a zero-initialised hitRec, as a fresh invocation would. */
+int ptmo_hit_scene(const ptmo_scene* scene, const ptmo_params* prm, int64_t n, const float* rays6,
+                   uint32_t* rng_inout, ptmo_hit* out, ptmo_stats* stats_out) {
+  if (!scene || !prm || !rays6 || !out || prm->stack_size <= 0 || prm->stack_size > 64) return -1;
+  float un[20] = {1, 1, 1, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  ptmo_stats total;
+  memset(&total, 0, sizeof total);
+  for (int64_t i = 0; i < n; i++) {
+    Thread t(scene, prm, un);
+    if (rng_inout) t.randState = rng_inout[i];
+    Ray r{V(rays6[6 * i], rays6[6 * i + 1], rays6[6 * i + 2]), V(rays6[6 * i + 3], rays6[6 * i + 4], rays6[6 * i + 5])};
+    bool h = t.hitScene(r);
+    ptmo_hit& o = out[i];
+    memset(&o, 0, sizeof o);
+    o.hit = h ? 1 : 0;
+    o.t = t.hitRec.t;
+    o.p[0] = t.hitRec.p.x, o.p[1] = t.hitRec.p.y, o.p[2] = t.hitRec.p.z;
+    o.normal[0] = t.hitRec.normal.x, o.normal[1] = t.hitRec.normal.y, o.normal[2] = t.hitRec.normal.z;
+    o.front_face = t.hitRec.front_face ? 1 : 0;
+    memcpy(o.material, t.hitRec.material.raw, 64);
+    if (rng_inout) rng_inout[i] = t.randState;
+    add_stats(&total, t.st);
+  }
+  if (stats_out) *stats_out = total;
+  return 0;
+}
+
+/* Brute-force closest hit over ALL triangles in array order (the reference's commented-out
+ * hit_bruteForce, shaders/hitRay.wgsl:188-221) — used by the BVH-equivalence test. */
+int ptmo_hit_bruteforce(const ptmo_scene* scene, const ptmo_params* prm, int64_t n, const float* rays6, ptmo_hit* out) {
+  if (!scene || !prm || !rays6 || !out) return -1;
+  float un[20] = {1, 1, 1, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  for (int64_t i = 0; i < n; i++) {
+    Thread t(scene, prm, un);
+    Ray r{V(rays6[6 * i], rays6[6 * i + 1], rays6[6 * i + 2]), V(rays6[6 * i + 3], rays6[6 * i + 4], rays6[6 * i + 5])};
+    float closest = MAX_FLOAT;
+    bool h = false;
+    for (int k = 0; k < scene->n_triangles; k++) {
+      if (t.hit_triangle(scene->triangles + 24 * (size_t)k, t.ray_tmin, closest, r)) {
+        h = true;
+        closest = t.hitRec.t;
+      }
+    }
+    ptmo_hit& o = out[i];
+    memset(&o, 0, sizeof o);
+    o.hit = h ? 1 : 0;
+    o.t = t.hitRec.t;
+    o.p[0] = t.hitRec.p.x, o.p[1] = t.hitRec.p.y, o.p[2] = t.hitRec.p.z;
+    o.normal[0] = t.hitRec.normal.x, o.normal[1] = t.hitRec.normal.y, o.normal[2] = t.hitRec.normal.z;
+    o.front_face = t.hitRec.front_face ? 1 : 0;
+    memcpy(o.material, t.hitRec.material.raw, 64);
+  }
+  return 0;
+}
+
+/* PCG stream: n draws of rand2D from `seed` (common.wgsl:7-12); also returns the raw u32 numerators. */
+int ptmo_rand(uint32_t seed, int n, float* out_f, uint32_t* out_state) {
+  ptmo_scene sc;
+  memset(&sc, 0, sizeof sc);
+  ptmo_params pr;
+  memset(&pr, 0, sizeof pr);
+  pr.stack_size = 1;
+  float un[20] = {0};
+  Thread t(&sc, &pr, un);
+  t.randState = seed;
+  for (int i = 0; i < n; i++) {
+    float f = t.rand2D();
+    if (out_f) out_f[i] = f;
+    if (out_state) out_state[i] = t.randState;
+  }
+  return 0;
+}
+
+/* elementwise ptm_* evaluation: fn 0 sin, 1 cos, 2 acos, 3 log, 4 log2, 5 exp2, 6 pow(x,y), 7 sqrt */
+int ptmo_math(int fn, int64_t n, const float* x, const float* y, float* out) {
+  for (int64_t i = 0; i < n; i++) {
+    float a = x[i], b = y ? y[i] : 0.0f, r;
+    switch (fn) {
+      case 0: r = ptm_sin(a); break;
+      case 1: r = ptm_cos(a); break;
+      case 2: r = ptm_acos(a); break;
+      case 3: r = ptm_log(a); break;
+      case 4: r = ptm_log2(a); break;
+      case 5: r = ptm_exp2(a); break;
+      case 6: r = ptm_pow(a, b); break;
+      case 7: r = ptm_sqrt(a); break;
+      default: return -1;
+    }
+    out[i] = r;
+  }
+  return 0;
+}
+
+int ptmo_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+}
