@@ -1,0 +1,174 @@
+/*
+ * ptmi.h — C ABI of libptmi.so, the MI355X-native path-tracing integrator.
+ *
+ * The reference (Shridhar2602/WebGPU-Path-Tracer) has no FFI: its device boundary is WebGPU itself —
+ * `class WebGPU` (webgpu-utils.js:1-212) as driven by `class Renderer` (renderer.js:68-124,163-215):
+ * create a storage buffer from a typed array (x8), write 80 bytes of uniforms, dispatch ONE compute
+ * entry point `computeFrameBuffer` (shaders/main.wgsl:1) per frame.  Each entry point below names the
+ * reference call it replaces.  All buffers use the reference's own byte layouts;
+ * the library copies on upload and never keeps caller pointers.
+ *
+ * A context is single-caller (not thread-safe) and bound to ONE GPU; multi-GPU = one process (or one
+ * context) per GPU with disjoint pixel tiles (ptmi_set_shard) and one sum-reduce of the framebuffers.
+ * Every call returns PTMI_OK (0) or a negative ptmi_status; ptmi_last_error() gives the message.
+ */
+#ifndef PTMI_H
+#define PTMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTMI_API_VERSION 1
+
+typedef struct ptmi_ctx ptmi_ctx;
+
+typedef enum ptmi_status {
+  PTMI_OK = 0,
+  PTMI_ERR_INVALID_ARG = -1, /* null pointer, bad size/stride, bad enum                      */
+  PTMI_ERR_DEVICE = -2,      /* a HIP call failed (message carries hipGetErrorString)        */
+  PTMI_ERR_STATE = -3,       /* call order: render before resize, size mismatch with uniforms */
+  PTMI_ERR_NO_MEMORY = -4,   /* host or device allocation failed                             */
+  PTMI_ERR_BAD_SCENE = -5,   /* an index in the uploaded buffers is out of range / BVH not a tree */
+  PTMI_ERR_UNSUPPORTED = -6  /* parameter combination outside the supported set               */
+} ptmi_status;
+
+/* Buffer ids = the WGSL @binding numbers of shaders/header.wgsl:15-23 (binding 0 = uniforms and
+ * binding 3 = framebuffer have their own calls; binding 4 is unused in the reference too). */
+typedef enum ptmi_buffer {
+  PTMI_BUF_SPHERES = 1,    /*  8 f32 / sphere   — renderer.js:93,  lib/primitives/sphere.js:25-29  */
+  PTMI_BUF_QUADS = 2,      /* 20 f32 / quad     — renderer.js:95,  lib/primitives/quad.js:21-36    */
+  PTMI_BUF_TRIANGLES = 5,  /* 24 f32 / triangle — renderer.js:99,  lib/primitives/triangle.js:42-52 */
+  PTMI_BUF_MESHES = 6,     /*  4 i32 / mesh     — renderer.js:94,  lib/primitives/mesh.js:58-63    */
+  PTMI_BUF_TRANSFORMS = 7, /* 32 f32 / object   — renderer.js:97,  lib/transform.js:38-40          */
+  PTMI_BUF_MATERIALS = 8,  /* 16 f32 / material — renderer.js:96,  lib/scene.js:261-273            */
+  PTMI_BUF_BVH = 9         /* 12 f32 / node     — renderer.js:98,  lib/BVH/bvhBuilder.js:37-54     */
+} ptmi_buffer;
+
+/* The reference's compile-time knobs (shaders/header.wgsl:9-13, traceRay.wgsl:8, main.wgsl:7) as
+ * run-time parameters.  ptmi_default_params() fills the reference's values. */
+typedef struct ptmi_params {
+  int32_t num_samples;         /* NUM_SAMPLES = 1                                             */
+  int32_t max_bounces;         /* MAX_BOUNCES = 100                                           */
+  int32_t stratify;            /* STRATIFY = false                                            */
+  int32_t importance_sampling; /* IMPORTANCE_SAMPLING = false                                 */
+  int32_t stack_size;          /* STACK_SIZE = 20 (traversal aborts when the stack fills, Q7) */
+  float background[3];         /* (0,1,1)                                                     */
+  float fov_degrees;           /* 60                                                          */
+  int32_t frames_in_flight;    /* ptmi_render batches this many frames per wavefront pass; 0 = auto */
+  int32_t reserved[5];
+} ptmi_params;
+
+/* Exact work counters (device-side when ptmi_set_counters(ctx,1); `rays` and `paths` always) and
+ * GPU timings (HIP events on the context's stream when ptmi_set_timing(ctx,1)). Cumulative since
+ * ptmi_reset_stats. */
+typedef struct ptmi_stats {
+  uint64_t rays;         /* hitScene invocations (shaders/hitRay.wgsl:1)                      */
+  uint64_t paths;        /* ray_color invocations (shaders/traceRay.wgsl:3)                   */
+  uint64_t node_visits;  /* hit_aabb calls the REFERENCE traversal makes for these rays       */
+  uint64_t tri_tests;    /* hit_triangle calls                                                */
+  uint64_t sphere_tests; /* hit_sphere + hit_volume calls                                     */
+  uint64_t quad_tests;   /* hit_quad calls                                                    */
+  uint64_t mat_fetches;  /* `hitRec.material = materials[..]` executions                      */
+  uint64_t frames;       /* frames rendered                                                   */
+  uint64_t intersect_launches;
+  uint64_t shade_launches;
+  double render_ms;      /* generate..accumulate, all batches                                 */
+  double intersect_ms;   /* sum over intersect launches                                       */
+  double shade_ms;       /* sum over shade launches                                           */
+  double other_ms;       /* generate + accumulate                                             */
+} ptmi_stats;
+
+/* One hitScene result, the fields of the reference's HitRecord (shaders/header.wgsl:119-125). */
+typedef struct ptmi_hit {
+  int32_t hit;
+  float t;
+  float p[3];
+  float normal[3];
+  int32_t front_face;
+  float material[16];
+} ptmi_hit;
+
+int ptmi_version(void);
+const char* ptmi_status_string(int status);
+/* Message of the last failing call on this context ("" if none). ctx may be NULL: returns the
+ * message of the last failing ptmi_create in this thread. */
+const char* ptmi_last_error(const ptmi_ctx* ctx);
+
+/* replaces WebGPU.init() (webgpu-utils.js:178-211): binds device `device_id`, creates one stream */
+int ptmi_create(ptmi_ctx** out, int device_id);
+void ptmi_destroy(ptmi_ctx* ctx);
+
+void ptmi_default_params(ptmi_params* p);
+int ptmi_set_params(ptmi_ctx* ctx, const ptmi_params* p);
+int ptmi_get_params(const ptmi_ctx* ctx, ptmi_params* p);
+
+/* replaces createStorageBuffer_WriteOnly(label, typedArray) (webgpu-utils.js:29-41, renderer.js:93-99):
+ * copies `bytes` bytes (a multiple of the buffer's stride; 0 allowed = empty array). */
+int ptmi_upload(ptmi_ctx* ctx, int which, const void* data, size_t bytes);
+
+/* replaces createStorageBuffer_ReadWrite('frameNum buffer', Float32Array(W*H*4).fill(0))
+ * (renderer.js:88,100): allocates and zeroes the W*H RGBA f32 accumulation buffer. */
+int ptmi_resize(ptmi_ctx* ctx, int width, int height);
+int ptmi_clear_framebuffer(ptmi_ctx* ctx);
+
+/* Pixel-tile sharding for multi-GPU: this context renders only pixels p with
+ * (p / tile_pixels) % world == rank; other pixels of its framebuffer stay untouched (zero). */
+int ptmi_set_shard(ptmi_ctx* ctx, int rank, int world, int tile_pixels);
+
+/* replaces queue.writeBuffer(uniforms) + computePass(...) of one animation frame
+ * (renderer.js:173-188, webgpu-utils.js:125-134): uniforms20 = [W, H, frameNum, resetBuffer,
+ * viewMatrix[16] column-major].  Asynchronous; ordering = call order. */
+int ptmi_render_frame(ptmi_ctx* ctx, const float* uniforms20);
+
+/* n_frames consecutive ptmi_render_frame calls with frameNum = first_frame .. first_frame+n_frames-1,
+ * resetBuffer = 0 and a fixed view matrix — the progressive-rendering steady state
+ * (renderer.js:163-184), batched so that several frames are in flight per wavefront pass.
+ * Result is bit-identical to the frame-by-frame calls. */
+int ptmi_render(ptmi_ctx* ctx, const float* view16, uint32_t first_frame, uint32_t n_frames);
+
+int ptmi_synchronize(ptmi_ctx* ctx);
+
+/* Framebuffer access (the reference never reads back; COPY_SRC exists, webgpu-utils.js:47).
+ * read/write synchronise the stream; bytes must be W*H*16. */
+int ptmi_read_framebuffer(ptmi_ctx* ctx, float* rgba_sum, size_t bytes);
+int ptmi_write_framebuffer(ptmi_ctx* ctx, const float* rgba_sum, size_t bytes);
+/* Device pointer of the accumulation buffer (for an in-place RCCL reduce by the host program). */
+int ptmi_framebuffer_device_ptr(ptmi_ctx* ctx, void** dev_ptr, size_t* bytes);
+/* Use caller-owned device memory (>= W*H*16 bytes, 16-byte aligned) as the accumulation buffer. */
+int ptmi_bind_framebuffer(ptmi_ctx* ctx, void* dev_ptr, size_t bytes);
+/* hipStream_t the context launches on (as void*), so callers can record their own HIP events. */
+int ptmi_stream(ptmi_ctx* ctx, void** stream);
+
+/* Display pass (shaders/fragment.js:22-36, shaders/common.wgsl:273-282): color = fb/frameNum ->
+ * ACES approximation -> pow(1/2.2) -> RGBA8.  dst = W*H*4 bytes on the host. */
+int ptmi_resolve_rgba8(ptmi_ctx* ctx, float frame_num, uint8_t* dst, size_t bytes);
+
+int ptmi_set_counters(ptmi_ctx* ctx, int enabled);
+int ptmi_set_timing(ptmi_ctx* ctx, int enabled);
+int ptmi_get_stats(ptmi_ctx* ctx, ptmi_stats* out); /* synchronises */
+int ptmi_reset_stats(ptmi_ctx* ctx);
+
+/* Test hook: hitScene (shaders/hitRay.wgsl:1-113) for n caller-supplied rays (6 f32 each: origin,
+ * dir), each with its own RNG state (consumed by hit_volume only; may be NULL). */
+int ptmi_trace(ptmi_ctx* ctx, size_t n, const float* rays6, uint32_t* rng_inout, ptmi_hit* out);
+/* Test hook: evaluates include/ptmi_math.h functions ON THE DEVICE.
+ * fn: 0 sin 1 cos 2 acos 3 log 4 log2 5 exp2 6 pow(x,y) 7 sqrt 8 min(x,y) 9 max(x,y) 10 x/y */
+int ptmi_math_eval(ptmi_ctx* ctx, int fn, size_t n, const float* x, const float* y, float* out);
+
+/* ---- host-side natives (no GPU needed) -------------------------------------------------------- */
+
+/* Median-split BVH build + pre-order flatten with the reference's exact semantics
+ * (lib/BVH/bvhNode.js:21-101, lib/BVH/bvhBuilder.js:6-54): prim boxes as n x 3 doubles each;
+ * writes (2n-1) x 12 f32 nodes and the primitive permutation (order[k] = input index of the
+ * primitive stored at position k). */
+int ptmi_build_bvh(size_t n_prims, const double* bmin, const double* bmax, int prim_type, float* nodes_out,
+                   int64_t* order_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTMI_H */

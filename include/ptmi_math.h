@@ -15,7 +15,8 @@
  *   - host builds want -mfma so that fmaf() is one instruction (libm's fmaf is also exact, only slow).
  *
  * Accuracy (checked by tests/test_math.py against float64 libm): sin/cos <= 2 ulp on [-64, 64],
- * acos <= 3 ulp, log <= 2 ulp, log2/exp2 <= 2 ulp, pow(x,5) <= 16 ulp on (0,1].
+ * acos <= 2 ulp, log/log2/exp2 <= 1 ulp; pow(x,y) = exp2(y*log2(x)) by definition (WGSL), so its error
+ * grows with |y*log2(x)| (about 65 ulp for x^5 near 1e-6, where the value itself is ~1e-30).
  */
 #ifndef PTMI_MATH_H
 #define PTMI_MATH_H
@@ -45,10 +46,27 @@ PTM_HD float ptm_u2f(uint32_t u) {
   return f;
 }
 
-/* min/max with a fixed NaN rule (WGSL leaves it open, SURVEY.md §8a-W last row):
- * min(a,b) = b < a ? b : a ; max(a,b) = a < b ? b : a  — a NaN in `b` is dropped, a NaN in `a` stays. */
-PTM_HD float ptm_min(float a, float b) { return (b < a) ? b : a; }
-PTM_HD float ptm_max(float a, float b) { return (a < b) ? b : a; }
+/* min/max: WGSL "if one operand is a NaN, the other is returned"; additionally -0 < +0.  That is
+ * exactly what gfx950's v_min_f32 / v_max_f32 (and the fused v_min3/v_max3) compute, so the device
+ * uses the hardware instruction and the host spells the same rule out.  The rule is associative and
+ * commutative, hence independent of how a compiler nests a 3-way min/max. */
+#if defined(__HIP_DEVICE_COMPILE__)
+PTM_HD float ptm_min(float a, float b) { return __builtin_fminf(a, b); }
+PTM_HD float ptm_max(float a, float b) { return __builtin_fmaxf(a, b); }
+#else
+PTM_HD float ptm_min(float a, float b) {
+  if (a != a) return b;
+  if (b != b) return a;
+  if (a == b) return (ptm_f2u(a) >> 31) ? a : b; /* min(-0,+0) = -0 */
+  return (a < b) ? a : b;
+}
+PTM_HD float ptm_max(float a, float b) {
+  if (a != a) return b;
+  if (b != b) return a;
+  if (a == b) return (ptm_f2u(a) >> 31) ? b : a; /* max(-0,+0) = +0 */
+  return (a < b) ? b : a;
+}
+#endif
 
 /* round to nearest integer (ties to even) for |x| < 2^22, by the add-magic trick: only + and - */
 PTM_HD float ptm_rint_small(float x) {

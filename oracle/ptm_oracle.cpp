@@ -817,7 +817,8 @@ int ptmo_rand(uint32_t seed, int n, float* out_f, uint32_t* out_state) {
   return 0;
 }
 
-/* elementwise ptm_* evaluation: fn 0 sin, 1 cos, 2 acos, 3 log, 4 log2, 5 exp2, 6 pow(x,y), 7 sqrt */
+/* elementwise ptm_* evaluation: fn 0 sin, 1 cos, 2 acos, 3 log, 4 log2, 5 exp2, 6 pow(x,y), 7 sqrt,
+ * 8 min(x,y), 9 max(x,y), 10 x/y */
 int ptmo_math(int fn, int64_t n, const float* x, const float* y, float* out) {
   for (int64_t i = 0; i < n; i++) {
     float a = x[i], b = y ? y[i] : 0.0f, r;
@@ -830,6 +831,9 @@ int ptmo_math(int fn, int64_t n, const float* x, const float* y, float* out) {
       case 5: r = ptm_exp2(a); break;
       case 6: r = ptm_pow(a, b); break;
       case 7: r = ptm_sqrt(a); break;
+      case 8: r = ptm_min(a, b); break;
+      case 9: r = ptm_max(a, b); break;
+      case 10: r = a / b; break;
       default: return -1;
     }
     out[i] = r;

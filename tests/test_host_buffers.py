@@ -1,0 +1,109 @@
+"""Host-side scene code vs goldens captured from the reference's own JavaScript
+(oracle/capture/capture.mjs -> tests/golden/).  Byte-exact."""
+import hashlib
+import math
+import os
+
+import numpy as np
+import pytest
+
+ASSETS = "/root/reference/assets"  # only present in the build container; never on the GPU box
+needs_assets = pytest.mark.skipif(not os.path.isdir(ASSETS), reason="reference assets not mounted")
+
+
+def _same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.size == b.size and np.array_equal(a.reshape(-1).view(np.uint32), b.reshape(-1).view(np.uint32))
+
+
+def test_c1_buffers_match_reference_js(pkg):
+    b = pkg.scenes.c1_scene().buffers()
+    g = pkg.scenes.golden_buffers("c1")
+    for k in pkg.scenes.BUFFER_NAMES:
+        assert _same(b[k], g[k]), k
+
+
+@needs_assets
+@pytest.mark.parametrize("native", [False, True])
+def test_mesh_scenes_match_reference_js(pkg, native):
+    from webgpu_path_tracer_amd.host import ObjReader
+
+    nat = pkg.ptmi.NativeHost() if native else None
+    cube = ObjReader.load_model(ASSETS + "/cube.obj")
+    cases = {
+        "default": pkg.scenes.DefaultScene(cube),
+        "c2": pkg.scenes.c2_scene(ObjReader.load_model(ASSETS + "/monkey_968.obj")),
+        "c2m": pkg.scenes.c2m_scene(ObjReader.load_model(ASSETS + "/icosphere.obj"), cube),
+    }
+    for name, sc in cases.items():
+        b = sc.buffers(native=nat)
+        g = pkg.scenes.golden_buffers(name)
+        for k in pkg.scenes.BUFFER_NAMES:
+            assert _same(b[k], g[k]), (name, k)
+
+
+@needs_assets
+def test_obj_reader_matches_reference_js(pkg):
+    from webgpu_path_tracer_amd.host import ObjReader
+
+    cube = ObjReader.load_model(ASSETS + "/cube.obj")
+    for k in ("vertices", "normals"):
+        g = np.fromfile(os.path.join(pkg.scenes.GOLDEN_DIR, "objcube_%s.bin" % k), np.float32)
+        assert _same(cube[k], g), k
+
+
+@needs_assets
+@pytest.mark.parametrize("tag,fname", [("m5802", "monkey_5802.obj"), ("m15744", "monkey_smooth_15744.obj")])
+def test_large_mesh_bvh_hashes(pkg, tag, fname):
+    """5.8k / 15.7k triangle meshes: sha256 of bvh / triangles / transforms equal the reference's."""
+    from webgpu_path_tracer_amd.host import ObjReader
+
+    man = pkg.scenes.golden_manifest()[tag]
+    sc = pkg.scenes.mesh_scene(ObjReader.load_model(os.path.join(ASSETS, fname)), scale=(1.1, 1.1, 1.1), rotate=(math.pi / 4, [0, 1, 0]), translate=(0.65, -0.64, 0))
+    b = sc.buffers(native=pkg.ptmi.NativeHost())
+    for k in ("bvh", "triangles", "transforms"):
+        assert hashlib.sha256(np.ascontiguousarray(b[k]).tobytes()).hexdigest() == man[k]["sha256"], k
+
+
+def test_native_bvh_equals_python_builder_on_random_boxes(pkg):
+    from webgpu_path_tracer_amd.host import build_bvh
+
+    rng = np.random.default_rng(7)
+    for n in (1, 2, 3, 17, 256, 1000):
+        c = rng.uniform(-1, 1, (n, 3)).astype(np.float32).astype(np.float64)
+        c[rng.integers(0, n, n // 3)] = c[0]  # duplicate keys exercise sort stability
+        e = rng.uniform(0, 0.1, (n, 3))
+        a, oa = build_bvh(c - e, c + e)
+        b, ob = build_bvh(c - e, c + e, native=pkg.ptmi.NativeHost())
+        assert np.array_equal(oa, ob) and _same(a, b), n
+
+
+def test_cameras_match_reference_js(pkg):
+    man = pkg.scenes.golden_manifest()["cameras"]
+    for k, (eye, center) in pkg.scenes.CAMERAS.items():
+        assert _same(pkg.scenes.camera_view(eye, center), np.array(man[k]["viewMatrix"], np.float32)), k
+
+
+def test_gl_matrix_known_answers(pkg):
+    """gl-matrix boundary is unpinned by the reference (CDN import): closed-form checks."""
+    from webgpu_path_tracer_amd.host.glmatrix import mat4, vec3
+
+    m = mat4.create()
+    mat4.fromRotation(m, math.pi / 2, [0, 0, 1])
+    v = vec3.transformMat4(vec3.create(), [1, 0, 0], m)
+    assert np.allclose(v, [0, 1, 0], atol=1e-7)
+    t, s, r = mat4.create(), mat4.create(), mat4.create()
+    mat4.fromTranslation(t, [1, 2, 3])
+    mat4.fromScaling(s, [2, 2, 2])
+    mat4.multiply(r, t, s)  # scale then translate
+    assert np.allclose(vec3.transformMat4(vec3.create(), [1, 1, 1], r), [3, 4, 5])
+    inv = mat4.create()
+    mat4.invert(inv, r)
+    ident = mat4.create()
+    mat4.multiply(ident, inv, r)
+    assert np.allclose(ident, np.eye(4).reshape(16), atol=1e-6)
+    sing = np.zeros(16, np.float32)
+    assert mat4.invert(mat4.create(), sing) is None
+    cam = mat4.create()
+    mat4.targetTo(cam, [0, 0, 5], [0, 0, 0], [0, 1, 0])
+    assert np.allclose(cam, [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 5, 1])

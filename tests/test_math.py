@@ -1,0 +1,78 @@
+"""include/ptmi_math.h: accuracy of the pinned transcendental functions against float64 libm (CPU),
+and bit-identity of the device evaluation with the host evaluation (GPU)."""
+import numpy as np
+import pytest
+
+from conftest import assert_same_bits
+
+FN = {"sin": 0, "cos": 1, "acos": 2, "log": 3, "log2": 4, "exp2": 5, "pow": 6, "sqrt": 7, "min": 8, "max": 9, "div": 10}
+
+
+def _ulps(got, ref64):
+    ref32 = ref64.astype(np.float32)
+    ulp = np.spacing(np.abs(ref32)).astype(np.float64)
+    ulp[ulp == 0] = np.finfo(np.float32).tiny
+    return np.abs(got.astype(np.float64) - ref64) / ulp
+
+
+def _inputs(rng):
+    return {
+        "sin": np.concatenate([rng.uniform(-64, 64, 400000), np.linspace(0, 2 * np.pi, 200001)]).astype(np.float32),
+        "acos": np.concatenate([rng.uniform(-1, 1, 400000), np.linspace(-1, 1, 100001)]).astype(np.float32),
+        "log": np.concatenate([rng.uniform(0, 1, 400000), np.exp(rng.uniform(-80, 80, 200000)), np.arange(1, 50000) / 4294967296.0]).astype(np.float32),
+        "exp2": rng.uniform(-149, 128, 400000).astype(np.float32),
+    }
+
+
+def test_accuracy_against_float64(oracle):
+    rng = np.random.default_rng(0)
+    x = _inputs(rng)
+    assert _ulps(oracle.math_eval(FN["sin"], x["sin"]), np.sin(x["sin"].astype(np.float64))).max() <= 2.0
+    assert _ulps(oracle.math_eval(FN["cos"], x["sin"]), np.cos(x["sin"].astype(np.float64))).max() <= 2.0
+    assert _ulps(oracle.math_eval(FN["acos"], x["acos"]), np.arccos(x["acos"].astype(np.float64))).max() <= 2.0
+    lx = x["log"][x["log"] > 0]
+    assert _ulps(oracle.math_eval(FN["log"], lx), np.log(lx.astype(np.float64))).max() <= 1.0
+    assert _ulps(oracle.math_eval(FN["log2"], lx), np.log2(lx.astype(np.float64))).max() <= 1.5
+    assert _ulps(oracle.math_eval(FN["exp2"], x["exp2"]), np.exp2(x["exp2"].astype(np.float64))).max() <= 1.5
+    # pow(x,5) on the Schlick range (importanceSampling.wgsl:4): relative error 1e-5 is ample
+    b = rng.uniform(1e-3, 1, 200000).astype(np.float32)
+    got = oracle.math_eval(FN["pow"], b, np.full_like(b, 5))
+    assert np.max(np.abs(got / b.astype(np.float64) ** 5 - 1)) < 1e-5
+
+
+def test_special_values(oracle):
+    inf, nan = np.float32(np.inf), np.float32(np.nan)
+    r = oracle.math_eval(FN["log"], [0, -1, inf, nan, 1])
+    assert r[0] == -inf and np.isnan(r[1]) and r[2] == inf and np.isnan(r[3]) and r[4] == 0
+    r = oracle.math_eval(FN["pow"], [0, 1, 2, -1], [5, 5, 5, 5])
+    assert r[0] == 0 and r[1] == 1 and r[2] == 32 and np.isnan(r[3])
+    r = oracle.math_eval(FN["acos"], [1, -1, 1.0001, 0])
+    assert r[0] == 0 and r[1] == np.float32(np.pi) and np.isnan(r[2])
+    r = oracle.math_eval(FN["exp2"], [-200, 200, 0, -149])
+    assert r[0] == 0 and r[1] == inf and r[2] == 1 and r[3] == np.float32(2.0**-149)
+    # min/max rule: NaN -> other operand; -0 < +0
+    a = np.array([nan, 1, nan, -0.0, 0.0, 3], np.float32)
+    b = np.array([2, nan, nan, 0.0, -0.0, -3], np.float32)
+    mn, mx = oracle.math_eval(FN["min"], a, b), oracle.math_eval(FN["max"], a, b)
+    assert mn[0] == 2 and mn[1] == 1 and np.isnan(mn[2]) and np.signbit(mn[3]) and np.signbit(mn[4]) and mn[5] == -3
+    assert mx[0] == 2 and mx[1] == 1 and np.isnan(mx[2]) and not np.signbit(mx[3]) and not np.signbit(mx[4]) and mx[5] == 3
+
+
+@pytest.mark.gpu
+def test_device_math_is_bit_identical_to_host(ctx, oracle):
+    rng = np.random.default_rng(1)
+    x = _inputs(rng)
+    sp = np.array([0, -0.0, 1, -1, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 3.4e38, 1e-38, 0.5, -0.5, 2**-32, 1 - 2**-24], np.float32)
+    for name, arr in (("sin", x["sin"]), ("cos", x["sin"]), ("acos", x["acos"]), ("log", x["log"]), ("log2", x["log"]), ("exp2", x["exp2"]), ("sqrt", x["log"])):
+        a = np.concatenate([arr, sp])
+        assert_same_bits(ctx.math_eval(FN[name], a), oracle.math_eval(FN[name], a), name)
+    a = np.concatenate([rng.uniform(0, 1, 200000).astype(np.float32), sp])
+    for y in (5.0, 2.0, 1 / 2.2):
+        yy = np.full_like(a, y)
+        assert_same_bits(ctx.math_eval(FN["pow"], a, yy), oracle.math_eval(FN["pow"], a, yy), "pow %g" % y)
+    # min / max / division incl. every pair of special values
+    A, B = [m.reshape(-1) for m in np.meshgrid(sp, sp)]
+    A = np.concatenate([A, rng.normal(0, 10, 100000).astype(np.float32)])
+    B = np.concatenate([B, rng.normal(0, 10, 100000).astype(np.float32)])
+    for name in ("min", "max", "div"):
+        assert_same_bits(ctx.math_eval(FN[name], A, B), oracle.math_eval(FN[name], A, B), name)

@@ -1,0 +1,216 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle: bit-exact f32 framebuffers, hit records
+and work counters on seeded inputs, plus size-independent properties at BASELINE.json's full size.
+
+Tolerance: north_star asks for per-pixel L2 < 1e-4; the build targets and tests BIT-EXACT equality
+(NaNs compared as NaN), which implies it."""
+import numpy as np
+import pytest
+
+from conftest import assert_same_bits, cornell_view
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(ctx, pkg, name, w, h, **params):
+    b = pkg.scenes.golden_buffers(name)
+    ctx.upload_scene(b)
+    ctx.set_params(**params)
+    ctx.resize(w, h)
+    return b
+
+
+def _oracle_params(p):
+    return {k: v for k, v in p.items() if k != "frames_in_flight"}
+
+
+CASES = [
+    # name, camera, W, H, frames, params                                              (BASELINE configs[0] first)
+    ("c1", "cornell", 256, 256, 4, dict(max_bounces=4)),
+    ("c2", "cornell", 320, 180, 4, dict(max_bounces=8)),
+    ("c2m", "cornell", 192, 128, 3, dict(max_bounces=12, stack_size=20)),
+    ("default", "default", 180, 120, 3, dict(max_bounces=16)),
+    ("c2m", "oblique", 160, 96, 2, dict(max_bounces=8, importance_sampling=1)),
+    ("c1", "cornell", 128, 128, 2, dict(max_bounces=6, importance_sampling=1)),
+    ("c2", "cornell", 96, 64, 2, dict(max_bounces=5, num_samples=3)),
+    ("c2m", "cornell", 96, 64, 2, dict(max_bounces=5, num_samples=4, stratify=1)),
+    ("c2", "oblique", 128, 72, 2, dict(max_bounces=8, stack_size=4)),  # Q7 abort active
+    ("c2", "cornell", 64, 48, 1, dict(max_bounces=0)),
+    ("c2", "cornell", 100, 37, 2, dict(max_bounces=3, background=(0.3, 0.2, 0.9), fov_degrees=75.0)),  # W*H not a multiple of 64
+]
+
+
+@pytest.mark.parametrize("name,cam,w,h,frames,params", CASES, ids=[f"{c[0]}-{c[1]}-{i}" for i, c in enumerate(CASES)])
+def test_framebuffer_bit_exact(ctx, pkg, oracle, name, cam, w, h, frames, params):
+    b = _setup(ctx, pkg, name, w, h, **params)
+    view = cornell_view(pkg, cam)
+    ctx.reset_stats()
+    ctx.set_counters(True)
+    ctx.render(view, 1, frames)
+    got = ctx.read_framebuffer()
+    st = ctx.stats()
+    ctx.set_counters(False)
+    want, ost = oracle.render(b, w, h, view, 1, frames, **_oracle_params(params))
+    assert_same_bits(got, want, name)
+    for k in ("rays", "paths", "node_visits", "tri_tests", "sphere_tests", "quad_tests", "mat_fetches"):
+        assert st[k] == ost[k], (k, st[k], ost[k])
+
+
+def test_render_frame_equals_batched_render_and_reset(ctx, pkg, oracle):
+    b = _setup(ctx, pkg, "c2m", 96, 64, max_bounces=6, frames_in_flight=3)
+    view = cornell_view(pkg)
+    ctx.render(view, 1, 5)
+    batched = ctx.read_framebuffer()
+    ctx.clear()
+    for f in range(1, 6):
+        ctx.render_frame(np.concatenate([[96, 64, f, 0], view]).astype(np.float32))
+    assert_same_bits(ctx.read_framebuffer(), batched, "frame-by-frame")
+    # resetBuffer = 1 (camera moved, renderer.js:174): the sample overwrites the running sum
+    ctx.render_frame(np.concatenate([[96, 64, 9, 1], view]).astype(np.float32))
+    want, _ = oracle.render(b, 96, 64, view, 9, 1, max_bounces=6)
+    assert_same_bits(ctx.read_framebuffer(), want, "reset")
+    with pytest.raises(pkg.PtmiError):
+        ctx.render_frame(np.concatenate([[95, 64, 1, 0], view]).astype(np.float32))
+
+
+def _rays(rng, n):
+    o = rng.uniform(-0.3, 0.3, (n, 3)) + np.array([0, -0.1, 2.4])
+    tgt = rng.uniform(-1.0, 1.0, (n, 3)) * np.array([1.2, 1.0, 0.9])
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    inside_o = rng.uniform(-0.95, 0.95, (n, 3))
+    inside_d = rng.normal(0, 1, (n, 3))  # not normalised on purpose
+    return np.concatenate([np.concatenate([o, d], 1), np.concatenate([inside_o, inside_d], 1)]).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c2m", "default"])
+def test_hit_records_bit_exact(ctx, pkg, oracle, name):
+    b = pkg.scenes.golden_buffers(name)
+    ctx.upload_scene(b)
+    ctx.set_params(stack_size=20)
+    rng = np.random.default_rng(11)
+    rays = _rays(rng, 20000)
+    seeds = rng.integers(0, 2**32, rays.shape[0], dtype=np.uint64).astype(np.uint32)
+    got, grng = ctx.trace(rays, seeds)
+    want, wrng, _ = oracle.hit_scene(b, rays, seeds, stack_size=20)
+    assert np.array_equal(got["hit"], want["hit"])
+    m = want["hit"] == 1
+    assert m.sum() > 1000
+    for f in ("t", "p", "normal", "material"):
+        assert_same_bits(got[f][m], want[f][m], f"{name}.{f}")
+    assert np.array_equal(got["front_face"][m], want["front_face"][m])
+    assert np.array_equal(grng, wrng)  # hit_volume's RNG draws (common.wgsl:134) happen at the same points
+
+
+def test_degenerate_rays(ctx, pkg, oracle):
+    """Zero / axis-aligned / non-finite directions: inf and NaN flow as in the scalar evaluation (Q4)."""
+    b = pkg.scenes.golden_buffers("c2m")
+    ctx.upload_scene(b)
+    ctx.set_params()
+    z = np.float32(0)
+    rays = np.array([
+        [0, 0, 2.5, 0, 0, -1], [0, 0, 2.5, 0, 0, 0], [0, 0, 0, 1, 0, 0], [0, 0, 0, 0, 1, 0], [0, -1, 0, 0, 0, -1],
+        [0, 0, 2.5, np.nan, 0, -1], [0, 0, 2.5, np.inf, 0, -1], [-1, -1, -1, 1, 1, 1], [1, 0.5, 0, -1, 0, 0], [0, 0, 2.5, -z, -z, -1],
+    ], np.float32)
+    got, _ = ctx.trace(rays, np.arange(10, dtype=np.uint32))
+    want, _, _ = oracle.hit_scene(b, rays, np.arange(10, dtype=np.uint32))
+    assert np.array_equal(got["hit"], want["hit"])
+    m = want["hit"] == 1
+    for f in ("t", "p", "normal"):
+        assert_same_bits(got[f][m], want[f][m], f)
+
+
+def test_upload_validation_errors(ctx, pkg):
+    b = dict(pkg.scenes.golden_buffers("c2"))
+    with pytest.raises(pkg.PtmiError) as e:
+        ctx.upload("bvh", np.zeros(13, np.float32))
+    assert e.value.status == -1
+    bad = b["bvh"].copy()
+    bad[3] = 5_000_000.0  # root's right child out of range
+    ctx.upload_scene({**b, "bvh": bad})
+    ctx.resize(8, 8)
+    with pytest.raises(pkg.PtmiError) as e:
+        ctx.render(cornell_view(pkg), 1, 1)
+    assert e.value.status == -5
+    loop = b["bvh"].copy()
+    loop[12 + 3] = loop[3]  # left child of the root claims the root's right child: node reachable twice
+    ctx.upload_scene({**b, "bvh": loop})
+    with pytest.raises(pkg.PtmiError) as e:
+        ctx.render(cornell_view(pkg), 1, 1)
+    assert e.value.status == -5
+    q = b["quads"].copy()
+    q[19] = 99.0
+    ctx.upload_scene({**b, "quads": q})
+    with pytest.raises(pkg.PtmiError):
+        ctx.render(cornell_view(pkg), 1, 1)
+    ctx.upload_scene(b)
+    ctx.render(cornell_view(pkg), 1, 1)  # recovers
+    ctx.synchronize()
+
+
+def test_empty_scene_and_sharding(ctx, pkg, oracle):
+    z = np.zeros(0, np.float32)
+    ctx.upload_scene({"spheres": z, "quads": z, "triangles": z, "meshes": np.zeros(0, np.int32), "transforms": z, "materials": z, "bvh": z})
+    ctx.set_params(max_bounces=3)
+    ctx.resize(33, 7)
+    ctx.render(cornell_view(pkg), 1, 2)
+    fb = ctx.read_framebuffer()
+    assert np.array_equal(fb.reshape(-1, 4), np.tile(np.array([0, 2, 2, 1], np.float32), (33 * 7, 1)))
+    # pixel-tile shards: disjoint, and their sum is the full image bit for bit (x + 0 = x)
+    b = _setup(ctx, pkg, "c2", 200, 120, max_bounces=6)
+    view = cornell_view(pkg)
+    ctx.render(view, 1, 3)
+    full = ctx.read_framebuffer()
+    acc = np.zeros_like(full)
+    for world, tile in ((2, 64), (3, 50)):
+        acc[:] = 0
+        cover = np.zeros(full.shape[:2], int)
+        for r in range(world):
+            ctx.set_shard(r, world, tile)
+            ctx.clear()
+            ctx.render(view, 1, 3)
+            part = ctx.read_framebuffer()
+            cover += part[..., 3] == 1.0
+            acc += part
+        ctx.set_shard(0, 1, 64)
+        acc[..., 3] = 1.0
+        assert (cover == 1).all()
+        assert_same_bits(acc, full, f"world {world}")
+
+
+def test_full_size_properties_1080p(ctx, pkg, oracle):
+    """BASELINE configs[1] at full size (1920x1080, 8 bounces): frame-split invariance, a pixel-range
+    crop against the oracle, checkpoint round trip, exact ray accounting."""
+    W, H = 1920, 1080
+    b = _setup(ctx, pkg, "c2", W, H, max_bounces=8)
+    view = cornell_view(pkg)
+    ctx.reset_stats()
+    ctx.render(view, 1, 12)
+    a = ctx.read_framebuffer()
+    st = ctx.stats()
+    assert st["paths"] == W * H * 12 and st["rays"] >= st["paths"] and st["frames"] == 12
+    assert np.isfinite(a).all() and (a[..., 3] == 1.0).all()
+    # same frames in different batch splits, resumed through a host round trip of the framebuffer
+    ctx.set_params(max_bounces=8, frames_in_flight=5)
+    ctx.clear()
+    ctx.render(view, 1, 7)
+    saved = ctx.read_framebuffer()
+    ctx.clear()
+    ctx.write_framebuffer(saved)
+    ctx.render(view, 8, 5)
+    assert_same_bits(ctx.read_framebuffer(), a, "split/resume")
+    # oracle on a 6000-pixel window of the full-size image (middle rows, across the mesh)
+    p0 = (H // 2) * W + 700
+    want, _ = oracle.render(b, W, H, view, 1, 12, max_bounces=8, pixel_range=(p0, p0 + 6000))
+    assert_same_bits(a.reshape(-1, 4)[p0 : p0 + 6000], want.reshape(-1, 4)[p0 : p0 + 6000], "1080p crop")
+
+
+def test_resolve_rgba8(ctx, pkg):
+    _setup(ctx, pkg, "c1", 64, 64, max_bounces=4)
+    ctx.render(cornell_view(pkg), 1, 4)
+    fb = ctx.read_framebuffer()
+    img = ctx.resolve_rgba8(4)
+    c = fb[..., :3].astype(np.float64) / 4
+    v1 = c * 0.6
+    ref = np.clip((v1 * (2.51 * v1 + 0.03)) / (v1 * (2.43 * v1 + 0.59) + 0.14), 0, 1) ** (1 / 2.2)
+    assert img.shape == (64, 64, 4) and (img[..., 3] == 255).all()
+    assert np.abs(img[..., :3].astype(np.float64) - ref * 255).max() <= 1.0

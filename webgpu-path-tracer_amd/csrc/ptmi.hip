@@ -1,0 +1,806 @@
+// ptmi.hip — libptmi.so: context management, scene upload/validation/digests, wavefront scheduling and
+// the C ABI of include/ptmi.h.  gfx950 (MI355X) only; build: see webgpu-path-tracer_amd/_build.py.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ptmi.h"
+#include "ptmi_kernels.h"
+
+using namespace ptmi;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    if (bytes == 0) return hipSuccess;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+enum TimerTag { T_INTERSECT = 0, T_SHADE = 1, T_OTHER = 2, T_RENDER = 3, T_NTAGS = 4 };
+
+}  // namespace
+
+struct ptmi_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  ptmi_params prm;
+  int num_cus = 256;
+
+  // host copies of the uploaded arrays (reference layouts)
+  std::vector<float> h_spheres, h_quads, h_tris, h_xforms, h_mats, h_bvh;
+  std::vector<int32_t> h_meshes;
+  bool scene_dirty = true;
+
+  DBuf d_spheres, d_sphere_info, d_quads, d_quad_mat, d_tris, d_pretri, d_meshes, d_xforms, d_mats, d_nodes;
+  DevScene S{};
+  int bvh_depth = 0;             // max number of inner nodes on a root-to-leaf path
+  bool has_unknown_material = false;
+
+  int W = 0, H = 0;
+  DBuf d_fb_own;
+  float4* fb = nullptr;
+  size_t fb_bytes = 0;
+  int rank = 0, world = 1, tile = 64;
+
+  size_t path_cap = 0;
+  bool pixsum_alloc = false;
+  DBuf d_ray, d_thr, d_acc, d_pixsum, d_rng, d_hit, d_hitmat, d_q0, d_q1, d_bins, d_ctl, d_totals, d_scratch;
+  int ctl_cap = 0;
+
+  bool counters = false, timing = false;
+  ptmi_stats stats{};
+  std::vector<hipEvent_t> ev_pool;
+  struct Span {
+    hipEvent_t a, b;
+    int tag;
+  };
+  std::vector<Span> spans;
+};
+
+namespace {
+
+int fail(ptmi_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  else g_create_error = msg;
+  return code;
+}
+#define HIP_TRY(c, expr)                                                                              \
+  do {                                                                                                \
+    hipError_t _e = (expr);                                                                           \
+    if (_e != hipSuccess)                                                                             \
+      return fail((c), _e == hipErrorOutOfMemory ? PTMI_ERR_NO_MEMORY : PTMI_ERR_DEVICE,              \
+                  std::string(#expr) + ": " + hipGetErrorString(_e));                                 \
+  } while (0)
+
+hipEvent_t get_event(ptmi_ctx* c) {
+  if (!c->ev_pool.empty()) {
+    hipEvent_t e = c->ev_pool.back();
+    c->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+struct ScopedSpan {  // records a begin/end event pair around launches when timing is on
+  ptmi_ctx* c;
+  ptmi_ctx::Span s{};
+  bool on;
+  ScopedSpan(ptmi_ctx* c_, int tag) : c(c_), on(c_->timing) {
+    if (!on) return;
+    s.tag = tag;
+    s.a = get_event(c);
+    s.b = get_event(c);
+    (void)hipEventRecord(s.a, c->stream);
+  }
+  ~ScopedSpan() {
+    if (!on) return;
+    (void)hipEventRecord(s.b, c->stream);
+    c->spans.push_back(s);
+  }
+};
+void drain_spans(ptmi_ctx* c) {  // call after the stream is idle
+  for (auto& s : c->spans) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+      if (s.tag == T_INTERSECT) c->stats.intersect_ms += ms;
+      else if (s.tag == T_SHADE) c->stats.shade_ms += ms;
+      else if (s.tag == T_OTHER) c->stats.other_ms += ms;
+      else c->stats.render_ms += ms;
+    }
+    c->ev_pool.push_back(s.a);
+    c->ev_pool.push_back(s.b);
+  }
+  c->spans.clear();
+}
+
+size_t stride_of(int which) {
+  switch (which) {
+    case PTMI_BUF_SPHERES: return 32;
+    case PTMI_BUF_QUADS: return 80;
+    case PTMI_BUF_TRIANGLES: return 96;
+    case PTMI_BUF_MESHES: return 16;
+    case PTMI_BUF_TRANSFORMS: return 128;
+    case PTMI_BUF_MATERIALS: return 64;
+    case PTMI_BUF_BVH: return 48;
+  }
+  return 0;
+}
+
+bool id_from_float(float f, int n, int* out) {  // i32(f32) of an index field, range checked
+  if (!(f >= 0.0f) || !(f < 2147483000.0f)) return false;
+  int v = (int)f;
+  if (v >= n) return false;
+  *out = v;
+  return true;
+}
+
+// Validate every index the kernels will dereference and build the digests (see DevScene).
+int prepare_scene(ptmi_ctx* c) {
+  if (!c->scene_dirty) return PTMI_OK;
+  const int n_sph = (int)(c->h_spheres.size() / 8), n_quad = (int)(c->h_quads.size() / 20), n_tri = (int)(c->h_tris.size() / 24);
+  const int n_mesh = (int)(c->h_meshes.size() / 4), n_xf = (int)(c->h_xforms.size() / 32), n_mat = (int)(c->h_mats.size() / 16);
+  const int n_node = (int)(c->h_bvh.size() / 12);
+  char msg[256];
+
+  c->has_unknown_material = false;
+  for (int i = 0; i < n_mat; i++) {
+    float ty = c->h_mats[16 * (size_t)i + 14];
+    if (!(ty == 0.0f || ty == 1.0f || ty == 2.0f || ty == 3.0f)) c->has_unknown_material = true;
+  }
+  std::vector<int32_t> sphere_info(2 * (size_t)n_sph), quad_mat((size_t)n_quad);
+  for (int i = 0; i < n_sph; i++) {
+    int m;
+    if (!id_from_float(c->h_spheres[8 * (size_t)i + 6], n_mat, &m)) {
+      snprintf(msg, sizeof msg, "sphere %d: material_id out of range [0,%d)", i, n_mat);
+      return fail(c, PTMI_ERR_BAD_SCENE, msg);
+    }
+    float medium = c->h_mats[16 * (size_t)m + 14];
+    sphere_info[2 * (size_t)i] = m;
+    sphere_info[2 * (size_t)i + 1] = (medium < 3.0f) ? 0 : 1;  // hitRay.wgsl:8-9
+  }
+  int light = -1;
+  for (int i = 0; i < n_quad; i++) {
+    int m;
+    if (!id_from_float(c->h_quads[20 * (size_t)i + 19], n_mat, &m)) {
+      snprintf(msg, sizeof msg, "quad %d: material_id out of range [0,%d)", i, n_mat);
+      return fail(c, PTMI_ERR_BAD_SCENE, msg);
+    }
+    quad_mat[i] = m;
+    if (light < 0 && c->h_mats[16 * (size_t)m + 8] > 0.0f) light = i;  // common.wgsl:258-269
+  }
+  for (int i = 0; i < n_mesh; i++) {
+    const int32_t* me = &c->h_meshes[4 * (size_t)i];
+    if (me[2] < 0 || me[2] >= n_xf || me[3] < 0 || me[3] >= n_mat) {
+      snprintf(msg, sizeof msg, "mesh %d: global_id %d / material_id %d out of range (transforms %d, materials %d)", i, me[2], me[3], n_xf, n_mat);
+      return fail(c, PTMI_ERR_BAD_SCENE, msg);
+    }
+  }
+  // pretri digest: same f32 operations the shader performs per test (common.wgsl:199-201)
+  std::vector<float> pretri(16 * (size_t)n_tri);
+  for (int i = 0; i < n_tri; i++) {
+    const float* t = &c->h_tris[24 * (size_t)i];
+    int mesh;
+    if (!id_from_float(t[23], n_mesh, &mesh)) {
+      snprintf(msg, sizeof msg, "triangle %d: mesh_id out of range [0,%d)", i, n_mesh);
+      return fail(c, PTMI_ERR_BAD_SCENE, msg);
+    }
+    float* o = &pretri[16 * (size_t)i];
+    float ABx = t[4] - t[0], ABy = t[5] - t[1], ABz = t[6] - t[2];
+    float ACx = t[8] - t[0], ACy = t[9] - t[1], ACz = t[10] - t[2];
+    o[0] = t[0], o[1] = t[1], o[2] = t[2];
+    memcpy(&o[3], &mesh, 4);
+    o[4] = ABx, o[5] = ABy, o[6] = ABz, o[7] = 0.0f;
+    o[8] = ACx, o[9] = ACy, o[10] = ACz, o[11] = 0.0f;
+    o[12] = ABy * ACz - ABz * ACy;
+    o[13] = ABz * ACx - ABx * ACz;
+    o[14] = ABx * ACy - ABy * ACx;
+    o[15] = 0.0f;
+  }
+  // node32 digest + tree check.  Children always have larger indices than their parent (left = i+1,
+  // right > i+1), so a walk from the root terminates; "every node reached at most once" excludes
+  // shared subtrees (which could make a traversal exponentially long).
+  std::vector<float> node32(8 * (size_t)n_node);
+  c->bvh_depth = 0;
+  if (n_node > 0) {
+    std::vector<uint8_t> seen((size_t)n_node, 0);
+    std::vector<std::pair<int, int>> st;  // node, inner depth so far
+    st.emplace_back(0, 0);
+    while (!st.empty()) {
+      auto [i, depth] = st.back();
+      st.pop_back();
+      if (seen[i]) {
+        snprintf(msg, sizeof msg, "bvh: node %d reachable twice (not a tree)", i);
+        return fail(c, PTMI_ERR_BAD_SCENE, msg);
+      }
+      seen[i] = 1;
+      const float* nd = &c->h_bvh[12 * (size_t)i];
+      float* o = &node32[8 * (size_t)i];
+      o[0] = nd[0], o[1] = nd[1], o[2] = nd[2];
+      o[4] = nd[4], o[5] = nd[5], o[6] = nd[6];
+      int32_t a, b;
+      if ((int)nd[7] == 2) {  // leaf (hitRay.wgsl:45,56)
+        int first, cnt = (int)nd[9];
+        if (!(nd[9] >= 0.0f) || cnt < 0 || (cnt > 0 && (!id_from_float(nd[8], n_tri, &first) || first + cnt > n_tri))) {
+          snprintf(msg, sizeof msg, "bvh: leaf %d references triangles outside [0,%d)", i, n_tri);
+          return fail(c, PTMI_ERR_BAD_SCENE, msg);
+        }
+        a = cnt > 0 ? (int)nd[8] : 0;
+        b = (int32_t)((uint32_t)cnt | 0x80000000u);
+        c->bvh_depth = std::max(c->bvh_depth, depth);
+      } else {
+        int right, axis = (int)nd[11];
+        if (!id_from_float(nd[3], n_node, &right) || right <= i + 1 || i + 1 >= n_node || !(nd[11] >= 0.0f) || axis > 2) {
+          snprintf(msg, sizeof msg, "bvh: inner node %d has right_offset/axis out of range", i);
+          return fail(c, PTMI_ERR_BAD_SCENE, msg);
+        }
+        a = right;
+        b = axis;
+        st.emplace_back(right, depth + 1);
+        st.emplace_back(i + 1, depth + 1);
+      }
+      memcpy(&o[3], &a, 4);
+      memcpy(&o[7], &b, 4);
+    }
+  }
+
+  auto up = [&](DBuf& d, const void* src, size_t bytes) -> hipError_t {
+    hipError_t e = d.ensure(std::max<size_t>(bytes, 16));
+    if (e != hipSuccess) return e;
+    if (bytes) e = hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, c->stream);
+    return e;
+  };
+  HIP_TRY(c, up(c->d_spheres, c->h_spheres.data(), c->h_spheres.size() * 4));
+  HIP_TRY(c, up(c->d_sphere_info, sphere_info.data(), sphere_info.size() * 4));
+  HIP_TRY(c, up(c->d_quads, c->h_quads.data(), c->h_quads.size() * 4));
+  HIP_TRY(c, up(c->d_quad_mat, quad_mat.data(), quad_mat.size() * 4));
+  HIP_TRY(c, up(c->d_tris, c->h_tris.data(), c->h_tris.size() * 4));
+  HIP_TRY(c, up(c->d_pretri, pretri.data(), pretri.size() * 4));
+  HIP_TRY(c, up(c->d_meshes, c->h_meshes.data(), c->h_meshes.size() * 4));
+  HIP_TRY(c, up(c->d_xforms, c->h_xforms.data(), c->h_xforms.size() * 4));
+  HIP_TRY(c, up(c->d_mats, c->h_mats.data(), c->h_mats.size() * 4));
+  HIP_TRY(c, up(c->d_nodes, node32.data(), node32.size() * 4));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // the staging vectors die at scope exit
+
+  DevScene& S = c->S;
+  S.spheres = c->d_spheres.as<float4>();
+  S.sphere_info = c->d_sphere_info.as<int2>();
+  S.quads = c->d_quads.as<float4>();
+  S.quad_mat = c->d_quad_mat.as<int>();
+  S.tris = c->d_tris.as<float4>();
+  S.pretri = c->d_pretri.as<float4>();
+  S.meshes = c->d_meshes.as<int4>();
+  S.xforms = c->d_xforms.as<float4>();
+  S.mats = c->d_mats.as<float4>();
+  S.nodes = c->d_nodes.as<float4>();
+  S.n_spheres = n_sph, S.n_quads = n_quad, S.n_tris = n_tri, S.n_meshes = n_mesh, S.n_xforms = n_xf, S.n_mats = n_mat, S.n_nodes = n_node;
+  S.light_quad = light;
+  c->scene_dirty = false;
+  return PTMI_OK;
+}
+
+uint32_t count_local(uint32_t npix, int rank, int world, int tile) {
+  uint64_t n = 0;
+  uint64_t ntiles = ((uint64_t)npix + tile - 1) / tile;
+  for (uint64_t t = (uint64_t)rank; t < ntiles; t += (uint64_t)world) {
+    uint64_t b = t * tile, e = std::min<uint64_t>(b + tile, npix);
+    n += e - b;
+  }
+  return (uint32_t)n;
+}
+
+int ensure_paths(ptmi_ctx* c, size_t npaths, int n_ctl, bool need_pixsum) {
+  if (npaths > c->path_cap) {
+    HIP_TRY(c, c->d_ray.ensure(npaths * 32));
+    HIP_TRY(c, c->d_thr.ensure(npaths * 16));
+    HIP_TRY(c, c->d_acc.ensure(npaths * 16));
+    HIP_TRY(c, c->d_rng.ensure(npaths * 4));
+    HIP_TRY(c, c->d_hit.ensure(npaths * 16));
+    HIP_TRY(c, c->d_hitmat.ensure(npaths * 4));
+    HIP_TRY(c, c->d_q0.ensure(npaths * 4));
+    HIP_TRY(c, c->d_q1.ensure(npaths * 4));
+    HIP_TRY(c, c->d_bins.ensure(npaths * 4 * NUM_BINS));
+    c->path_cap = npaths;
+    c->pixsum_alloc = false;
+  }
+  if (need_pixsum && !c->pixsum_alloc) {
+    HIP_TRY(c, c->d_pixsum.ensure(c->path_cap * 16));
+    c->pixsum_alloc = true;
+  }
+  if (n_ctl > c->ctl_cap) {
+    HIP_TRY(c, c->d_ctl.ensure((size_t)n_ctl * sizeof(StepCtl)));
+    c->ctl_cap = n_ctl;
+  }
+  if (!c->d_totals.p) {
+    HIP_TRY(c, c->d_totals.ensure(8 * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMemsetAsync(c->d_totals.p, 0, 8 * sizeof(unsigned long long), c->stream));
+  }
+  return PTMI_OK;
+}
+
+Paths paths_of(ptmi_ctx* c, bool with_pixsum) {
+  Paths P;
+  P.ray = c->d_ray.as<float4>();
+  P.thr = c->d_thr.as<float4>();
+  P.acc = c->d_acc.as<float4>();
+  P.pixsum = with_pixsum ? c->d_pixsum.as<float4>() : nullptr;
+  P.rng = c->d_rng.as<uint32_t>();
+  P.hit = c->d_hit.as<float4>();
+  P.hitmat = c->d_hitmat.as<uint32_t>();
+  return P;
+}
+
+int stack_alloc_for(const ptmi_ctx* c) { return std::max(1, std::min(c->prm.stack_size, std::max(c->bvh_depth, 1))); }
+
+void launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, const uint32_t* q_in, uint32_t* bins, uint32_t cap, uint32_t max_items) {
+  int sa = stack_alloc_for(c);
+  size_t lds = (size_t)sa * kBlock * sizeof(int);
+  uint32_t want = (max_items + kBlock - 1) / kBlock;
+  uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(want, (uint32_t)c->num_cus * 8));
+  unsigned long long* tot = c->d_totals.as<unsigned long long>();
+  if (c->counters)
+    hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(kBlock), lds, c->stream, c->S, P, ctl, q_in, bins, cap, c->prm.stack_size, sa, tot);
+  else
+    hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(kBlock), lds, c->stream, c->S, P, ctl, q_in, bins, cap, c->prm.stack_size, sa, tot);
+}
+
+int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames, int reset_first) {
+  const ptmi_params& p = c->prm;
+  RenderConst rc{};
+  rc.W = (float)c->W;
+  rc.H = (float)c->H;
+  memcpy(rc.view, view16, 64);
+  rc.fov_factor = (float)(1.0 / std::tan((double)p.fov_degrees * (3.14159265358979323846 / 180.0) / 2.0));  // main.wgsl:7, folded in f64
+  rc.bg[0] = p.background[0], rc.bg[1] = p.background[1], rc.bg[2] = p.background[2];
+  rc.max_bounces = p.max_bounces;
+  rc.stratify = p.stratify ? 1 : 0;
+  if (p.stratify) {  // shootRay.wgsl:9-31
+    float sqrt_spp = (float)std::sqrt((double)p.num_samples);
+    int side = 0;
+    for (float i = 0.0f; i < sqrt_spp; i += 1.0f) side++;
+    rc.strat_side = side;
+    rc.recip_sqrt_spp = 1.0f / (float)(int)sqrt_spp;
+    rc.num_samples = side * side;
+    rc.sample_div = (float)(side * side);
+  } else {
+    rc.strat_side = 1;
+    rc.recip_sqrt_spp = 1.0f;
+    rc.num_samples = p.num_samples;
+    rc.sample_div = (float)p.num_samples;
+  }
+  rc.stack_size = p.stack_size;
+  rc.npix = (uint32_t)c->W * (uint32_t)c->H;
+  rc.frame0 = frame0;
+  rc.n_frames = n_frames;
+  rc.reset_first = reset_first;
+  rc.rank = c->rank, rc.world = c->world, rc.tile = c->tile;
+  rc.n_local = count_local(rc.npix, c->rank, c->world, c->tile);
+  if (rc.n_local == 0) return PTMI_OK;
+
+  const int n_steps = rc.num_samples * p.max_bounces;
+  const size_t npaths = (size_t)rc.npix * (size_t)n_frames;
+  int rcode = ensure_paths(c, npaths, n_steps + 2, rc.num_samples > 1);
+  if (rcode) return rcode;
+  Paths P = paths_of(c, rc.num_samples > 1);
+  StepCtl* ctl = c->d_ctl.as<StepCtl>();
+  const uint32_t cap = (uint32_t)c->path_cap;
+  const uint32_t total = rc.n_local * (uint32_t)n_frames;
+  uint32_t* q[2] = {c->d_q0.as<uint32_t>(), c->d_q1.as<uint32_t>()};
+  const uint32_t ew_grid = std::max<uint32_t>(1, std::min<uint32_t>((total + kBlock - 1) / kBlock, (uint32_t)c->num_cus * 16));
+
+  ScopedSpan whole(c, T_RENDER);
+  {
+    ScopedSpan s(c, T_OTHER);
+    HIP_TRY(c, hipMemsetAsync(ctl, 0, (size_t)(n_steps + 2) * sizeof(StepCtl), c->stream));
+    hipLaunchKernelGGL(k_generate, dim3(ew_grid), dim3(kBlock), 0, c->stream, rc, P, q[0], ctl);
+  }
+  for (int s = 0; s < n_steps; s++) {
+    {
+      ScopedSpan sp(c, T_INTERSECT);
+      launch_intersect(c, P, ctl + s, q[s & 1], c->d_bins.as<uint32_t>(), cap, total);
+    }
+    {
+      ScopedSpan sp(c, T_SHADE);
+      if (p.importance_sampling)
+        hipLaunchKernelGGL(k_shade<true>, dim3(ew_grid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, c->d_bins.as<uint32_t>(), cap, q[(s + 1) & 1]);
+      else
+        hipLaunchKernelGGL(k_shade<false>, dim3(ew_grid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, c->d_bins.as<uint32_t>(), cap, q[(s + 1) & 1]);
+    }
+    c->stats.intersect_launches++;
+    c->stats.shade_launches++;
+  }
+  {
+    ScopedSpan s(c, T_OTHER);
+    hipLaunchKernelGGL(k_accumulate, dim3(ew_grid), dim3(kBlock), 0, c->stream, rc, P, c->fb, ctl, n_steps, c->d_totals.as<unsigned long long>());
+  }
+  HIP_TRY(c, hipGetLastError());
+  c->stats.frames += (uint64_t)n_frames;
+  return PTMI_OK;
+}
+
+int check_renderable(ptmi_ctx* c) {
+  if (!c->fb || c->W <= 0) return fail(c, PTMI_ERR_STATE, "no framebuffer: call ptmi_resize first");
+  const ptmi_params& p = c->prm;
+  if (p.importance_sampling && c->has_unknown_material)
+    return fail(c, PTMI_ERR_UNSUPPORTED,
+                "importance_sampling with a material_type outside {0,1,2,3}: the shader would read stale private state (scatterRec)");
+  return PTMI_OK;
+}
+
+uint32_t u32_of_f32(float f) {  // WGSL u32(f32): truncation, clamped to the u32 range
+  if (!(f > 0.0f)) return 0u;
+  if (f >= 4294967296.0f) return 0xffffffffu;
+  return (uint32_t)f;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptmi_version(void) { return PTMI_API_VERSION; }
+
+const char* ptmi_status_string(int s) {
+  switch (s) {
+    case PTMI_OK: return "ok";
+    case PTMI_ERR_INVALID_ARG: return "invalid argument";
+    case PTMI_ERR_DEVICE: return "device (HIP) error";
+    case PTMI_ERR_STATE: return "invalid state / call order";
+    case PTMI_ERR_NO_MEMORY: return "out of memory";
+    case PTMI_ERR_BAD_SCENE: return "scene buffers failed validation";
+    case PTMI_ERR_UNSUPPORTED: return "unsupported parameter combination";
+  }
+  return "unknown status";
+}
+
+const char* ptmi_last_error(const ptmi_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+void ptmi_default_params(ptmi_params* p) {
+  if (!p) return;
+  memset(p, 0, sizeof *p);
+  p->num_samples = 1;
+  p->max_bounces = 100;
+  p->stratify = 0;
+  p->importance_sampling = 0;
+  p->stack_size = 20;
+  p->background[0] = 0.0f, p->background[1] = 1.0f, p->background[2] = 1.0f;
+  p->fov_degrees = 60.0f;
+  p->frames_in_flight = 0;
+}
+
+int ptmi_create(ptmi_ctx** out, int device_id) {
+  if (!out) return fail(nullptr, PTMI_ERR_INVALID_ARG, "ptmi_create: out is null");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail(nullptr, PTMI_ERR_DEVICE, std::string("no HIP device available: ") + hipGetErrorString(e));
+  if (device_id < 0 || device_id >= n) return fail(nullptr, PTMI_ERR_INVALID_ARG, "ptmi_create: device_id out of range");
+  HIP_TRY(nullptr, hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device_id));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return fail(nullptr, PTMI_ERR_DEVICE, std::string("libptmi is built for gfx950 (MI355X) only; device is ") + prop.gcnArchName);
+  ptmi_ctx* c = new (std::nothrow) ptmi_ctx();
+  if (!c) return fail(nullptr, PTMI_ERR_NO_MEMORY, "ptmi_create: host allocation failed");
+  c->device = device_id;
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  ptmi_default_params(&c->prm);
+  e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete c;
+    return fail(nullptr, PTMI_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+  }
+  *out = c;
+  return PTMI_OK;
+}
+
+void ptmi_destroy(ptmi_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  drain_spans(c);
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+  for (DBuf* b : {&c->d_spheres, &c->d_sphere_info, &c->d_quads, &c->d_quad_mat, &c->d_tris, &c->d_pretri, &c->d_meshes, &c->d_xforms,
+                  &c->d_mats, &c->d_nodes, &c->d_fb_own, &c->d_ray, &c->d_thr, &c->d_acc, &c->d_pixsum, &c->d_rng, &c->d_hit, &c->d_hitmat,
+                  &c->d_q0, &c->d_q1, &c->d_bins, &c->d_ctl, &c->d_totals, &c->d_scratch})
+    b->release();
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int ptmi_set_params(ptmi_ctx* c, const ptmi_params* p) {
+  if (!c || !p) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_set_params: null argument");
+  if (p->num_samples < 1 || p->max_bounces < 0 || p->stack_size < 1 || p->stack_size > 64 || p->frames_in_flight < 0)
+    return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_set_params: need num_samples >= 1, max_bounces >= 0, 1 <= stack_size <= 64, frames_in_flight >= 0");
+  if ((int64_t)p->num_samples * p->max_bounces > 65536)
+    return fail(c, PTMI_ERR_UNSUPPORTED, "ptmi_set_params: num_samples * max_bounces > 65536");
+  if (!(p->fov_degrees > 0.0f && p->fov_degrees < 180.0f)) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_set_params: fov_degrees must be in (0,180)");
+  c->prm = *p;
+  return PTMI_OK;
+}
+
+int ptmi_get_params(const ptmi_ctx* c, ptmi_params* p) {
+  if (!c || !p) return PTMI_ERR_INVALID_ARG;
+  *p = c->prm;
+  return PTMI_OK;
+}
+
+int ptmi_upload(ptmi_ctx* c, int which, const void* data, size_t bytes) {
+  if (!c) return PTMI_ERR_INVALID_ARG;
+  size_t stride = stride_of(which);
+  if (!stride) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_upload: unknown buffer id");
+  if (bytes % stride) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_upload: byte size is not a multiple of the buffer's stride");
+  if (bytes && !data) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_upload: data is null");
+  if (bytes / stride > 0x0fffffffull) return fail(c, PTMI_ERR_UNSUPPORTED, "ptmi_upload: more than 2^28-1 elements");
+  const float* f = (const float*)data;
+  switch (which) {
+    case PTMI_BUF_SPHERES: c->h_spheres.assign(f, f + bytes / 4); break;
+    case PTMI_BUF_QUADS: c->h_quads.assign(f, f + bytes / 4); break;
+    case PTMI_BUF_TRIANGLES: c->h_tris.assign(f, f + bytes / 4); break;
+    case PTMI_BUF_MESHES: c->h_meshes.assign((const int32_t*)data, (const int32_t*)data + bytes / 4); break;
+    case PTMI_BUF_TRANSFORMS: c->h_xforms.assign(f, f + bytes / 4); break;
+    case PTMI_BUF_MATERIALS: c->h_mats.assign(f, f + bytes / 4); break;
+    case PTMI_BUF_BVH: c->h_bvh.assign(f, f + bytes / 4); break;
+  }
+  c->scene_dirty = true;
+  return PTMI_OK;
+}
+
+int ptmi_resize(ptmi_ctx* c, int width, int height) {
+  if (!c) return PTMI_ERR_INVALID_ARG;
+  if (width <= 0 || height <= 0 || (int64_t)width * height > (1ll << 28))
+    return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_resize: need 0 < W*H <= 2^28");
+  HIP_TRY(c, hipSetDevice(c->device));
+  size_t bytes = (size_t)width * height * 16;
+  HIP_TRY(c, c->d_fb_own.ensure(bytes));
+  c->fb = c->d_fb_own.as<float4>();
+  c->fb_bytes = bytes;
+  c->W = width;
+  c->H = height;
+  HIP_TRY(c, hipMemsetAsync(c->fb, 0, bytes, c->stream));
+  return PTMI_OK;
+}
+
+int ptmi_clear_framebuffer(ptmi_ctx* c) {
+  if (!c || !c->fb) return fail(c, PTMI_ERR_STATE, "ptmi_clear_framebuffer: no framebuffer");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemsetAsync(c->fb, 0, c->fb_bytes, c->stream));
+  return PTMI_OK;
+}
+
+int ptmi_set_shard(ptmi_ctx* c, int rank, int world, int tile_pixels) {
+  if (!c) return PTMI_ERR_INVALID_ARG;
+  if (world < 1 || rank < 0 || rank >= world || tile_pixels < 1) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_set_shard: need 0 <= rank < world, tile_pixels >= 1");
+  c->rank = rank, c->world = world, c->tile = tile_pixels;
+  return PTMI_OK;
+}
+
+int ptmi_render_frame(ptmi_ctx* c, const float* u) {
+  if (!c || !u) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_render_frame: null argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int r = prepare_scene(c);
+  if (r) return r;
+  r = check_renderable(c);
+  if (r) return r;
+  if (u[0] != (float)c->W || u[1] != (float)c->H) return fail(c, PTMI_ERR_STATE, "ptmi_render_frame: uniforms screenDims differ from ptmi_resize");
+  return render_batch(c, u + 4, u32_of_f32(u[2]), 1, u[3] == 0.0f ? 0 : 1);
+}
+
+int ptmi_render(ptmi_ctx* c, const float* view16, uint32_t first_frame, uint32_t n_frames) {
+  if (!c || !view16) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_render: null argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int r = prepare_scene(c);
+  if (r) return r;
+  r = check_renderable(c);
+  if (r) return r;
+  size_t npix = (size_t)c->W * c->H;
+  uint32_t F = c->prm.frames_in_flight > 0 ? (uint32_t)c->prm.frames_in_flight : 8u;
+  size_t max_f = std::max<size_t>(1, (size_t)0x0fffffff / npix);  // path ids stay below 2^28
+  F = (uint32_t)std::min<size_t>(F, max_f);
+  for (uint32_t done = 0; done < n_frames;) {
+    uint32_t nb = std::min(F, n_frames - done);
+    r = render_batch(c, view16, first_frame + done, (int)nb, 0);
+    if (r) return r;
+    done += nb;
+  }
+  return PTMI_OK;
+}
+
+int ptmi_synchronize(ptmi_ctx* c) {
+  if (!c) return PTMI_ERR_INVALID_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_spans(c);
+  return PTMI_OK;
+}
+
+int ptmi_read_framebuffer(ptmi_ctx* c, float* dst, size_t bytes) {
+  if (!c || !dst) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_read_framebuffer: null argument");
+  if (!c->fb) return fail(c, PTMI_ERR_STATE, "ptmi_read_framebuffer: no framebuffer");
+  if (bytes != (size_t)c->W * c->H * 16) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_read_framebuffer: bytes != W*H*16");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(dst, c->fb, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_spans(c);
+  return PTMI_OK;
+}
+
+int ptmi_write_framebuffer(ptmi_ctx* c, const float* src, size_t bytes) {
+  if (!c || !src) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_write_framebuffer: null argument");
+  if (!c->fb) return fail(c, PTMI_ERR_STATE, "ptmi_write_framebuffer: no framebuffer");
+  if (bytes != (size_t)c->W * c->H * 16) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_write_framebuffer: bytes != W*H*16");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(c->fb, src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return PTMI_OK;
+}
+
+int ptmi_framebuffer_device_ptr(ptmi_ctx* c, void** p, size_t* bytes) {
+  if (!c || !p) return PTMI_ERR_INVALID_ARG;
+  if (!c->fb) return fail(c, PTMI_ERR_STATE, "ptmi_framebuffer_device_ptr: no framebuffer");
+  *p = c->fb;
+  if (bytes) *bytes = (size_t)c->W * c->H * 16;
+  return PTMI_OK;
+}
+
+int ptmi_bind_framebuffer(ptmi_ctx* c, void* dev_ptr, size_t bytes) {
+  if (!c) return PTMI_ERR_INVALID_ARG;
+  if (c->W <= 0) return fail(c, PTMI_ERR_STATE, "ptmi_bind_framebuffer: call ptmi_resize first");
+  if (!dev_ptr || ((uintptr_t)dev_ptr & 15) || bytes < (size_t)c->W * c->H * 16)
+    return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_bind_framebuffer: need a 16-byte aligned device pointer of >= W*H*16 bytes");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->fb = (float4*)dev_ptr;
+  c->fb_bytes = (size_t)c->W * c->H * 16;
+  return PTMI_OK;
+}
+
+int ptmi_stream(ptmi_ctx* c, void** stream) {
+  if (!c || !stream) return PTMI_ERR_INVALID_ARG;
+  *stream = (void*)c->stream;
+  return PTMI_OK;
+}
+
+int ptmi_resolve_rgba8(ptmi_ctx* c, float frame_num, uint8_t* dst, size_t bytes) {
+  if (!c || !dst) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_resolve_rgba8: null argument");
+  if (!c->fb) return fail(c, PTMI_ERR_STATE, "ptmi_resolve_rgba8: no framebuffer");
+  size_t npix = (size_t)c->W * c->H;
+  if (bytes != npix * 4) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_resolve_rgba8: bytes != W*H*4");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, c->d_scratch.ensure(bytes));
+  hipLaunchKernelGGL(k_resolve_rgba8, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->fb, (uint32_t)npix, frame_num,
+                     c->d_scratch.as<uchar4>());
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(dst, c->d_scratch.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return PTMI_OK;
+}
+
+int ptmi_set_counters(ptmi_ctx* c, int on) {
+  if (!c) return PTMI_ERR_INVALID_ARG;
+  c->counters = on != 0;
+  return PTMI_OK;
+}
+int ptmi_set_timing(ptmi_ctx* c, int on) {
+  if (!c) return PTMI_ERR_INVALID_ARG;
+  c->timing = on != 0;
+  return PTMI_OK;
+}
+
+int ptmi_get_stats(ptmi_ctx* c, ptmi_stats* out) {
+  if (!c || !out) return PTMI_ERR_INVALID_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_spans(c);
+  if (c->d_totals.p) {
+    unsigned long long t[8];
+    HIP_TRY(c, hipMemcpy(t, c->d_totals.p, sizeof t, hipMemcpyDeviceToHost));
+    c->stats.rays = t[0], c->stats.paths = t[1], c->stats.node_visits = t[2], c->stats.tri_tests = t[3];
+    c->stats.sphere_tests = t[4], c->stats.quad_tests = t[5], c->stats.mat_fetches = t[6];
+  }
+  *out = c->stats;
+  return PTMI_OK;
+}
+
+int ptmi_reset_stats(ptmi_ctx* c) {
+  if (!c) return PTMI_ERR_INVALID_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_spans(c);
+  memset(&c->stats, 0, sizeof c->stats);
+  if (c->d_totals.p) HIP_TRY(c, hipMemset(c->d_totals.p, 0, 8 * sizeof(unsigned long long)));
+  return PTMI_OK;
+}
+
+int ptmi_trace(ptmi_ctx* c, size_t n, const float* rays6, uint32_t* rng_inout, ptmi_hit* out) {
+  if (!c || !rays6 || !out) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_trace: null argument");
+  if (n == 0) return PTMI_OK;
+  if (n > 0x0fffffffull) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_trace: too many rays");
+  static_assert(sizeof(HitOut) == sizeof(ptmi_hit), "hit record layouts must match");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int r = prepare_scene(c);
+  if (r) return r;
+  r = ensure_paths(c, n, 4, false);
+  if (r) return r;
+  Paths P = paths_of(c, false);
+  // stage: rays as 2 float4 each, identity queue
+  std::vector<float> stage(8 * n);
+  std::vector<uint32_t> ident(n), rng(n, 0u);
+  for (size_t i = 0; i < n; i++) {
+    for (int k = 0; k < 3; k++) stage[8 * i + k] = rays6[6 * i + k], stage[8 * i + 4 + k] = rays6[6 * i + 3 + k];
+    stage[8 * i + 3] = stage[8 * i + 7] = 0.0f;
+    ident[i] = (uint32_t)i;
+    if (rng_inout) rng[i] = rng_inout[i];
+  }
+  StepCtl ctl0{};
+  ctl0.n_rays = (uint32_t)n;
+  StepCtl* ctl = c->d_ctl.as<StepCtl>();
+  HIP_TRY(c, hipMemcpyAsync(P.ray, stage.data(), stage.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(P.rng, rng.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_q0.p, ident.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(ctl, &ctl0, sizeof ctl0, hipMemcpyHostToDevice, c->stream));
+  launch_intersect(c, P, ctl, c->d_q0.as<uint32_t>(), c->d_bins.as<uint32_t>(), (uint32_t)c->path_cap, (uint32_t)n);
+  HIP_TRY(c, c->d_scratch.ensure(n * sizeof(HitOut)));
+  hipLaunchKernelGGL(k_resolve_hits, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->S, P, (uint32_t)n, c->d_scratch.as<HitOut>());
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(out, c->d_scratch.p, n * sizeof(HitOut), hipMemcpyDeviceToHost, c->stream));
+  if (rng_inout) HIP_TRY(c, hipMemcpyAsync(rng_inout, P.rng, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return PTMI_OK;
+}
+
+int ptmi_math_eval(ptmi_ctx* c, int fn, size_t n, const float* x, const float* y, float* out) {
+  if (!c || !x || !out) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_math_eval: null argument");
+  if (fn < 0 || fn > 10) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_math_eval: unknown function id");
+  if (n == 0) return PTMI_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  DBuf dx, dy, dout;
+  HIP_TRY(c, dx.ensure(n * 4));
+  HIP_TRY(c, dout.ensure(n * 4));
+  if (y) HIP_TRY(c, dy.ensure(n * 4));
+  int rc = PTMI_OK;
+  do {
+    hipError_t e = hipMemcpyAsync(dx.p, x, n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && y) e = hipMemcpyAsync(dy.p, y, n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_math_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, fn, n, dx.as<float>(), y ? dy.as<float>() : nullptr,
+                         dout.as<float>());
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout.p, n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail(c, PTMI_ERR_DEVICE, std::string("ptmi_math_eval: ") + hipGetErrorString(e));
+  } while (0);
+  dx.release();
+  dy.release();
+  dout.release();
+  return rc;
+}
+
+}  // extern "C"

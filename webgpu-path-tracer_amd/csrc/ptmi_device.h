@@ -1,0 +1,557 @@
+// ptmi_device.h — device-side building blocks of the wavefront integrator (gfx950 only).
+//
+// Arithmetic rules: every float expression keeps the association of the WGSL source it implements
+// (cited per function, paths relative to the reference repo); this file is compiled with
+// -ffp-contract=off, so the only fused multiply-adds are the explicit ones inside ptmi_math.h and
+// the compiler's correctly-rounded division / sqrt expansions.  Results are bit-identical to a
+// scalar IEEE-754 evaluation of the shader.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ptmi_math.h"
+
+#define DEV __device__ __forceinline__
+
+namespace ptmi {
+
+// ---- constants of shaders/header.wgsl:1-13,37 (abstract-float consts folded in f64, rounded once) ----
+constexpr float kPi = 3.14159265358979323846;
+constexpr float kTwoPi = 2.0 * 3.14159265358979323846;
+constexpr float kMinFloat = 0.0001;
+constexpr float kMaxFloat = 999999999.999;        // 1.0e9f
+constexpr float kMaxFloatP1 = 999999999.999 + 1;  // also 1.0e9f: f32 ulp there is 64
+constexpr float kTmin = 0.000001;
+
+// hit kinds (upper 4 bits of the packed primitive word)
+enum : uint32_t { K_NONE = 0, K_SPHERE = 1, K_VOLUME = 2, K_QUAD = 3, K_TRI = 4 };
+// shade bins = material_type of the effective material; MISS paths get their own bin
+enum : int { BIN_LAMBERTIAN = 0, BIN_MIRROR = 1, BIN_GLASS = 2, BIN_ISOTROPIC = 3, BIN_OTHER = 4, BIN_MISS = 5, NUM_BINS = 6 };
+
+struct f3 {
+  float x, y, z;
+};
+DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+DEV f3 mk3(float4 v) { return f3{v.x, v.y, v.z}; }
+DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+DEV f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+DEV f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+DEV f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+DEV float len3(f3 a) { return ptm_sqrt(dot3(a, a)); }
+DEV f3 norm3(f3 a) { return a / len3(a); }
+DEV f3 mix3(f3 a, f3 b, float t) { return a * (1.0f - t) + b * t; }  // stays arithmetic (Q12)
+DEV f3 reflect3(f3 e1, f3 e2) { return e1 - (2.0f * dot3(e2, e1)) * e2; }
+DEV f3 refract3(f3 e1, f3 e2, float e3) {
+  float d = dot3(e2, e1);
+  float k = 1.0f - e3 * e3 * (1.0f - d * d);
+  if (k < 0.0f) return mk3(0, 0, 0);
+  return e3 * e1 - (e3 * d + ptm_sqrt(k)) * e2;
+}
+
+// column-major mat4 (4 float4 columns) times (v, w): ((c0*x + c1*y) + c2*z) + c3*w
+DEV float4 mat_mul(const float4* __restrict__ m, f3 v, float w) {
+  float4 c0 = m[0], c1 = m[1], c2 = m[2], c3 = m[3];
+  float4 r;
+  r.x = ((c0.x * v.x + c1.x * v.y) + c2.x * v.z) + c3.x * w;
+  r.y = ((c0.y * v.x + c1.y * v.y) + c2.y * v.z) + c3.y * w;
+  r.z = ((c0.z * v.x + c1.z * v.y) + c2.z * v.z) + c3.z * w;
+  r.w = ((c0.w * v.x + c1.w * v.y) + c2.w * v.z) + c3.w * w;
+  return r;
+}
+// transpose(m) * (v, 0): component i is the dot of column i with (v, 0)
+DEV f3 mat_mul_transposed_dir(const float4* __restrict__ m, f3 v) {
+  float4 c0 = m[0], c1 = m[1], c2 = m[2];
+  return mk3(((c0.x * v.x + c0.y * v.y) + c0.z * v.z) + c0.w * 0.0f, ((c1.x * v.x + c1.y * v.y) + c1.z * v.z) + c1.w * 0.0f,
+             ((c2.x * v.x + c2.y * v.y) + c2.z * v.z) + c2.w * 0.0f);
+}
+
+// shaders/common.wgsl:7-12
+DEV float rand2D(uint32_t& s) {
+  s = s * 747796405u + 2891336453u;
+  uint32_t word = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+  return (float)((word >> 22u) ^ word) / 4294967296.0f;
+}
+
+// ---- scene as the kernels see it -------------------------------------------------------------------
+// Raw arrays keep the reference's byte layout.  Two digests are derived at upload:
+//   node32 : {min.xyz, a} {max.xyz, b}   leaf: a = prim_id, b = prim_count | 0x80000000
+//                                          inner: a = right_offset, b = axis           (32 B, aligned)
+//   pretri : {A.xyz, mesh_id} {AB.xyz,0} {AC.xyz,0} {cross(AB,AC).xyz,0}                (64 B, aligned)
+// Both hold values the shader would compute itself (common.wgsl:199-201) — same f32 operations.
+struct DevScene {
+  const float4* spheres;  // 2 float4 / sphere
+  const int2* sphere_info;  // {material_id, is_volume}
+  const float4* quads;  // 5 float4 / quad
+  const int* quad_mat;
+  const float4* tris;    // 6 float4 / triangle (raw)
+  const float4* pretri;  // 4 float4 / triangle
+  const int4* meshes;
+  const float4* xforms;  // 8 float4 / object: model[4], invModel[4]
+  const float4* mats;    // 4 float4 / material
+  const float4* nodes;   // 2 float4 / node
+  int n_spheres, n_quads, n_tris, n_meshes, n_xforms, n_mats, n_nodes;
+  int light_quad;  // first quad with emission.x > 0 (common.wgsl:258-269), -1 if none
+};
+
+// ---- per-path state (arrays indexed by path id = frame_slot * npix + pixel) -----------------------------
+struct Paths {
+  float4* ray;      // 2 per path: {o.xyz, -} {d.xyz, -}
+  float4* thr;      // {T.xyz, bounce index as int bits}
+  float4* acc;      // {acc_radiance.xyz, sample index as int bits}; holds the final pixel colour at the end
+  float4* pixsum;   // {pixColor.xyz, -}  (num_samples > 1 only)
+  uint32_t* rng;    // randState
+  float4* hit;      // {t, u, v, kind<<28 | index}
+  uint32_t* hitmat; // effective material id (after hit_volume's clobber, Q3)
+};
+
+struct StepCtl {
+  uint32_t n_rays;  // entries in this step's ray queue
+  uint32_t head;    // fetch cursor of the persistent intersect kernel
+  uint32_t bin_n[NUM_BINS];
+};
+
+struct RenderConst {
+  float W, H;
+  float view[16];
+  float fov_factor;
+  float bg[3];
+  int max_bounces;
+  int num_samples;    // samples per pixel per frame actually traced (side*side when stratified)
+  int stratify;
+  int strat_side;
+  float recip_sqrt_spp;
+  float sample_div;   // divisor of pixColor (NUM_SAMPLES or numSamples)
+  int stack_size;
+  uint32_t npix;
+  uint32_t frame0;
+  int n_frames;
+  int reset_first;
+  // shard
+  uint32_t n_local;
+  int rank, world, tile;
+};
+
+DEV uint32_t local_to_pixel(const RenderConst& rc, uint32_t j) {
+  uint32_t tl = j / (uint32_t)rc.tile, within = j - tl * (uint32_t)rc.tile;
+  return (tl * (uint32_t)rc.world + (uint32_t)rc.rank) * (uint32_t)rc.tile + within;
+}
+
+// shaders/main.wgsl:3-8 + shaders/shootRay.wgsl:5-60: jittered camera ray for sample k of a pixel
+DEV void camera_ray(const RenderConst& rc, uint32_t pix, int k, uint32_t& rng, f3& o, f3& d) {
+  const float W = rc.W, H = rc.H;
+  float fidx = (float)pix;
+  float q = fidx / W;
+  float px = fidx - W * truncf(q);  // f32 %: x - y*trunc(x/y)
+  float py = q;                     // not floored (Q1)
+  float a, b;
+  if (rc.stratify) {
+    float i = (float)(k / rc.strat_side), j = (float)(k % rc.strat_side);
+    a = (W / H) * (2.0f * ((px - 0.5f + (rc.recip_sqrt_spp * (i + rand2D(rng)))) / W) - 1.0f);
+    b = -1.0f * (2.0f * ((py - 0.5f + (rc.recip_sqrt_spp * (j + rand2D(rng)))) / H) - 1.0f);
+  } else {
+    a = (W / H) * (2.0f * ((px - 0.5f + rand2D(rng)) / W) - 1.0f);
+    b = -1.0f * (2.0f * ((py - 0.5f + rand2D(rng)) / H) - 1.0f);
+  }
+  const float* m = rc.view;
+  float nf = -rc.fov_factor;
+  float dx = ((m[0] * a + m[4] * b) + m[8] * nf) + m[12] * 0.0f;
+  float dy = ((m[1] * a + m[5] * b) + m[9] * nf) + m[13] * 0.0f;
+  float dz = ((m[2] * a + m[6] * b) + m[10] * nf) + m[14] * 0.0f;
+  float dw = ((m[3] * a + m[7] * b) + m[11] * nf) + m[15] * 0.0f;
+  float len = ptm_sqrt(((dx * dx + dy * dy) + dz * dz) + dw * dw);  // normalize() of the vec4, then .xyz
+  d = mk3(dx / len, dy / len, dz / len);
+  // cam_origin = (view * (0,0,0,1)).xyz  (main.wgsl:8)
+  o = mk3(((m[0] * 0.0f + m[4] * 0.0f) + m[8] * 0.0f) + m[12] * 1.0f, ((m[1] * 0.0f + m[5] * 0.0f) + m[9] * 0.0f) + m[13] * 1.0f,
+          ((m[2] * 0.0f + m[6] * 0.0f) + m[10] * 0.0f) + m[14] * 1.0f);
+}
+
+// ---- closest-hit record carried in registers during hitScene ----------------------------------------
+struct Closest {
+  float t;        // closest_so_far
+  float u, v;     // barycentrics of the winning triangle
+  uint32_t prim;  // kind<<28 | index, K_NONE if nothing accepted yet
+  int mat;        // effective material id
+};
+
+struct Counters {
+  uint32_t node_visits, tri_tests, sphere_tests, quad_tests, mat_fetches;
+};
+
+// roots of shaders/common.wgsl:33-52 (hit_sphere) / :78-99 (hit_sphere_local); returns false on miss
+DEV bool sphere_root(f3 center, float r, float tmin, float tmax, f3 o, f3 d, float& root_out) {
+  f3 oc = o - center;
+  float a = dot3(d, d);
+  float half_b = dot3(d, oc);
+  float c = dot3(oc, oc) - r * r;
+  float disc = half_b * half_b - a * c;
+  if (disc < 0) return false;
+  float sqrtd = ptm_sqrt(disc);
+  float root = (-half_b - sqrtd) / a;
+  if (root <= tmin || root >= tmax) {
+    root = (-half_b + sqrtd) / a;
+    if (root <= tmin || root >= tmax) return false;
+  }
+  root_out = root;
+  return true;
+}
+
+// shaders/hitRay.wgsl:6-31 with hit_sphere (common.wgsl:29-73) and hit_volume (:102-146)
+template <bool COUNT>
+DEV void hit_spheres(const DevScene& S, f3 o, f3 d, uint32_t& rng, Closest& c, Counters& cn) {
+  for (int i = 0; i < S.n_spheres; i++) {
+    float4 s0 = S.spheres[2 * i];
+    int2 info = S.sphere_info[i];
+    f3 center = mk3(s0);
+    float r = s0.w;
+    if (COUNT) cn.sphere_tests++;
+    if (!info.y) {
+      float root;
+      if (sphere_root(center, r, kTmin, c.t, o, d, root)) {
+        c.t = root;
+        c.prim = (K_SPHERE << 28) | (uint32_t)i;
+        c.mat = info.x;
+        if (COUNT) cn.mat_fetches++;
+      }
+    } else {
+      float rec1, rec2;
+      if (!sphere_root(center, r, -kMaxFloat, kMaxFloat, o, d, rec1)) continue;  // == MAX_FLOAT + 1 sentinel
+      if (!sphere_root(center, r, rec1 + 0.0001f, kMaxFloat, o, d, rec2)) continue;
+      if (rec1 < kTmin) rec1 = kTmin;
+      if (rec2 > c.t) rec2 = c.t;
+      if (rec1 >= rec2) continue;
+      if (rec1 < 0) rec1 = 0;
+      c.mat = info.x;  // hitRec.material written before the final accept/reject (Q3)
+      if (COUNT) cn.mat_fetches++;
+      float roughness = S.mats[4 * info.x + 3].x;
+      float ray_length = len3(d);
+      float dist_inside = (rec2 - rec1) * ray_length;
+      float hit_dist = roughness * ptm_log(rand2D(rng));
+      if (hit_dist > dist_inside) continue;
+      c.t = rec1 + (hit_dist / ray_length);
+      c.prim = (K_VOLUME << 28) | (uint32_t)i;
+    }
+  }
+}
+
+// shaders/hitRay.wgsl:33-40 with hit_quad (common.wgsl:148-187)
+template <bool COUNT>
+DEV void hit_quads(const DevScene& S, f3 o, f3 d, Closest& c, Counters& cn) {
+  for (int i = 0; i < S.n_quads; i++) {
+    const float4* q = S.quads + 5 * i;
+    float4 q3 = q[3];
+    f3 n = mk3(q3);
+    if (COUNT) cn.quad_tests++;
+    if (dot3(d, n) > 0) continue;
+    float denom = dot3(n, d);
+    if (ptm_abs(denom) < 1e-8f) continue;
+    float t = (q3.w - dot3(n, o)) / denom;
+    if (t <= kTmin || t >= c.t) continue;
+    f3 isect = o + t * d;
+    f3 ph = isect - mk3(q[0]);
+    f3 w = mk3(q[4]);
+    float alpha = dot3(w, cross3(ph, mk3(q[2])));
+    float beta = dot3(w, cross3(mk3(q[1]), ph));
+    if (alpha < 0 || 1 < alpha || beta < 0 || 1 < beta) continue;
+    c.t = t;
+    c.prim = (K_QUAD << 28) | (uint32_t)i;
+    c.mat = S.quad_mat[i];
+    if (COUNT) cn.mat_fetches++;
+  }
+}
+
+// shaders/common.wgsl:245-256
+DEV bool hit_aabb(float4 lo, float4 hi, float tmax, f3 o, f3 inv) {
+  float t0x = (lo.x - o.x) * inv.x, t0y = (lo.y - o.y) * inv.y, t0z = (lo.z - o.z) * inv.z;
+  float t1x = (hi.x - o.x) * inv.x, t1y = (hi.y - o.y) * inv.y, t1z = (hi.z - o.z) * inv.z;
+  float sx = ptm_min(t0x, t1x), sy = ptm_min(t0y, t1y), sz = ptm_min(t0z, t1z);
+  float bx = ptm_max(t0x, t1x), by = ptm_max(t0y, t1y), bz = ptm_max(t0z, t1z);
+  float t_min = ptm_max(kTmin, ptm_max(sx, ptm_max(sy, sz)));
+  float t_max = ptm_min(tmax, ptm_min(bx, ptm_min(by, bz)));
+  return t_max > t_min;
+}
+
+// Object-space ray of shaders/common.wgsl:193-197, cached per mesh (it is a pure function of the
+// world ray and the mesh's invModelMatrix, so hoisting it out of the per-triangle test is exact).
+struct ObjRay {
+  f3 o, d;
+  int mesh;
+};
+DEV void obj_ray_for(const DevScene& S, int mesh, f3 o, f3 d, ObjRay& r) {
+  int gid = S.meshes[mesh].z;
+  const float4* inv = S.xforms + 8 * gid + 4;
+  float4 o4 = mat_mul(inv, o, 1.0f), d4 = mat_mul(inv, d, 0.0f);
+  r.o = mk3(o4);
+  r.d = mk3(d4);
+  r.mesh = mesh;
+}
+
+// shaders/common.wgsl:191-222 (the accept/reject part; normal, p and material are reconstructed
+// from (index, u, v) by resolve_hit once the closest hit is final)
+template <bool COUNT>
+DEV void hit_triangle(const DevScene& S, int k, f3 o, f3 d, ObjRay& orr, Closest& c, Counters& cn) {
+  const float4* pt = S.pretri + 4 * (size_t)k;
+  float4 t0 = pt[0], t1 = pt[1], t2 = pt[2], t3 = pt[3];
+  int mesh = __float_as_int(t0.w);
+  if (mesh != orr.mesh) obj_ray_for(S, mesh, o, d, orr);
+  if (COUNT) cn.tri_tests++;
+  f3 A = mk3(t0), AB = mk3(t1), AC = mk3(t2), N = mk3(t3);
+  float det = -dot3(orr.d, N);
+  if (ptm_abs(det) < kTmin) return;
+  f3 ao = orr.o - A;
+  f3 dao = cross3(ao, orr.d);
+  float invDet = 1.0f / det;
+  float dst = dot3(ao, N) * invDet;
+  float u = dot3(AC, dao) * invDet;
+  float v = -dot3(AB, dao) * invDet;
+  float w = 1.0f - u - v;
+  if (dst < kTmin || dst > c.t || u < kTmin || v < kTmin || w < kTmin) return;
+  c.t = dst;
+  c.u = u;
+  c.v = v;
+  c.prim = (K_TRI << 28) | (uint32_t)k;
+  c.mat = S.meshes[mesh].w;
+  if (COUNT) cn.mat_fetches++;
+}
+
+// shaders/hitRay.wgsl:42-110 — stack traversal, front-to-back by the split axis.  `stk` is this lane's
+// column of the LDS stack: entry d lives at stk[d * 64] (lane-major rows -> conflict-free ds_write/read).
+template <bool COUNT>
+DEV void traverse_bvh(const DevScene& S, f3 o, f3 d, int stack_size, int* __restrict__ stk, Closest& c, Counters& cn) {
+  if (S.n_nodes <= 0) return;  // no triangle geometry (an empty binding cannot exist in WebGPU)
+  f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  ObjRay orr;
+  orr.mesh = -1;
+  orr.o = orr.d = mk3(0, 0, 0);
+  int sp = 0, cur = 0;
+  while (true) {
+    float4 lo = S.nodes[2 * (size_t)cur], hi = S.nodes[2 * (size_t)cur + 1];
+    int a = __float_as_int(lo.w), b = __float_as_int(hi.w);
+    if (COUNT) cn.node_visits++;
+    if (hit_aabb(lo, hi, c.t, o, inv)) {
+      if (b < 0) {  // leaf
+        int cnt = b & 0x7fffffff;
+        for (int j = 0; j < cnt; j++) hit_triangle<COUNT>(S, a + j, o, d, orr, c, cn);
+        if (sp == 0) break;
+        sp--;
+        cur = stk[sp * 64];
+      } else {
+        float dax = (b == 0) ? d.x : ((b == 1) ? d.y : d.z);
+        if (dax < 0) {
+          stk[sp * 64] = cur + 1;
+          sp++;
+          cur = a;
+        } else {
+          stk[sp * 64] = a;
+          sp++;
+          cur = cur + 1;
+        }
+      }
+    } else {
+      if (sp == 0) break;
+      sp--;
+      cur = stk[sp * 64];
+    }
+    if (sp >= stack_size) break;  // hitRay.wgsl:106-109 (Q7)
+  }
+}
+
+// ---- HitRecord reconstruction (the accepting branch of the winning primitive test) ------------------
+struct HitGeom {
+  f3 p, n;
+  bool front;
+};
+DEV HitGeom resolve_hit(const DevScene& S, f3 o, f3 d, float t, float u, float v, uint32_t prim) {
+  HitGeom g;
+  uint32_t kind = prim >> 28, idx = prim & 0x0fffffffu;
+  g.p = o + t * d;  // at(ray, t)
+  if (kind == K_SPHERE) {  // common.wgsl:54-68
+    float4 s0 = S.spheres[2 * idx];
+    g.n = norm3((g.p - mk3(s0)) / s0.w);
+    g.front = dot3(d, g.n) < 0;
+    if (!g.front) g.n = -g.n;
+  } else if (kind == K_VOLUME) {  // common.wgsl:140-143
+    float4 s0 = S.spheres[2 * idx];
+    g.n = norm3(g.p - mk3(s0));
+    g.front = true;
+  } else if (kind == K_QUAD) {  // common.wgsl:176-183
+    g.n = norm3(mk3(S.quads[5 * idx + 3]));
+    g.front = dot3(d, g.n) < 0;
+    if (!g.front) g.n = -g.n;
+  } else {  // K_TRI, common.wgsl:224-237
+    const float4* tr = S.tris + 6 * (size_t)idx;
+    float4 nA = tr[3], nB = tr[4], nC = tr[5];
+    int mesh = (int)nC.w;
+    int gid = S.meshes[mesh].z;
+    float w = 1.0f - u - v;
+    f3 nn = mk3(nA) * w + mk3(nB) * u + mk3(nC) * v;
+    g.n = norm3(mat_mul_transposed_dir(S.xforms + 8 * gid + 4, nn));
+    g.front = dot3(d, g.n) < 0;
+    if (!g.front) g.n = -g.n;
+  }
+  return g;
+}
+
+// ---- sampling helpers (shaders/importanceSampling.wgsl) ---------------------------------------------
+struct Onb {
+  f3 u, v, w;
+};
+DEV Onb onb_build_from_w(f3 wdir) {  // :60-67
+  Onb b;
+  b.w = norm3(wdir);
+  f3 a = (ptm_abs(b.w.x) > 0.9f) ? mk3(0, 1, 0) : mk3(1, 0, 0);
+  b.v = norm3(cross3(b.w, a));
+  b.u = cross3(b.w, b.v);
+  return b;
+}
+DEV f3 onb_get_local(const Onb& b, f3 a) { return b.u * a.x + b.v * a.y + b.w * a.z; }  // :69-71
+DEV f3 uniform_random_in_unit_sphere(uint32_t& rng) {  // :7-16
+  float phi = rand2D(rng) * 2.0f * kPi;
+  float theta = ptm_acos(2.0f * rand2D(rng) - 1.0f);
+  float st = ptm_sin(theta);
+  float x = st * ptm_cos(phi);
+  float y = st * ptm_sin(phi);
+  float z = ptm_cos(theta);
+  return norm3(mk3(x, y, z));
+}
+DEV f3 cosine_sampling_wrt_Z(uint32_t& rng) {  // :35-45
+  float r1 = rand2D(rng);
+  float r2 = rand2D(rng);
+  float phi = kTwoPi * r1;
+  float sr = ptm_sqrt(r2);
+  return mk3(ptm_cos(phi) * sr, ptm_sin(phi) * sr, ptm_sqrt(1.0f - r2));
+}
+DEV float reflectance(float cosine, float ref_idx) {  // :1-5
+  float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+  r0 = r0 * r0;
+  return r0 + (1.0f - r0) * ptm_pow((1.0f - cosine), 5.0f);
+}
+
+struct QuadL {
+  f3 Q, u, v, normal, w;
+  float D;
+};
+DEV QuadL load_light(const DevScene& S) {
+  QuadL q;
+  if (S.light_quad < 0) {  // `lights` stays zero-initialised
+    q.Q = q.u = q.v = q.normal = q.w = mk3(0, 0, 0);
+    q.D = 0;
+    return q;
+  }
+  const float4* p = S.quads + 5 * S.light_quad;
+  q.Q = mk3(p[0]);
+  q.u = mk3(p[1]);
+  q.v = mk3(p[2]);
+  float4 n = p[3];
+  q.normal = mk3(n);
+  q.D = n.w;
+  q.w = mk3(p[4]);
+  return q;
+}
+// shaders/importanceSampling.wgsl:88-125 (quad argument == the global `lights` at the only call site)
+DEV float light_pdf(const QuadL& L, f3 ro, f3 rd) {
+  if (dot3(rd, L.normal) > 0) return kMinFloat;
+  float denom = dot3(L.normal, rd);
+  if (ptm_abs(denom) < 1e-8f) return kMinFloat;
+  float t = (L.D - dot3(L.normal, ro)) / denom;
+  if (t <= 0.001f || t >= kMaxFloat) return kMinFloat;
+  f3 isect = ro + t * rd;
+  f3 ph = isect - L.Q;
+  float alpha = dot3(L.w, cross3(ph, L.v));
+  float beta = dot3(L.w, cross3(L.u, ph));
+  if (alpha < 0 || 1 < alpha || beta < 0 || 1 < beta) return kMinFloat;
+  f3 hn = L.normal;
+  bool front = dot3(rd, L.normal) < 0;
+  if (!front) hn = -hn;
+  float dl = len3(rd);
+  float distance_squared = t * t * dl * dl;
+  float cosine = ptm_abs(dot3(rd, hn) / dl);
+  return distance_squared / (cosine * len3(cross3(L.u, L.v)));
+}
+
+struct Material {
+  f3 color, spec, emission;
+  float specularStrength, roughness, eta, type;
+};
+DEV Material load_material(const DevScene& S, int id) {
+  const float4* m = S.mats + 4 * id;
+  float4 a = m[0], b = m[1], c = m[2], e = m[3];
+  Material r;
+  r.color = mk3(a);
+  r.spec = mk3(b);
+  r.emission = mk3(c);
+  r.specularStrength = c.w;
+  r.roughness = e.x;
+  r.eta = e.y;
+  r.type = e.z;
+  return r;
+}
+
+// shaders/scatterRay.wgsl:2-95.  `bin` is the wave-uniform material class the path was sorted into.
+// Returns the scattered direction (origin is hitRec.p); sets doSpecular, skip_pdf and, for
+// LAMBERTIAN, the ONB w axis that onb_lambertian_scattering_pdf reads afterwards.
+DEV f3 material_scatter(int bin, const Material& m, const HitGeom& g, f3 din, uint32_t& rng, float& doSpecular, bool& skip_pdf, f3& unit_w) {
+  doSpecular = 0.0f;
+  skip_pdf = true;
+  if (bin == BIN_LAMBERTIAN) {
+    Onb b = onb_build_from_w(g.n);
+    unit_w = b.w;
+    f3 diffuse = cosine_sampling_wrt_Z(rng);
+    diffuse = norm3(onb_get_local(b, diffuse));
+    doSpecular = (rand2D(rng) < m.specularStrength) ? 1.0f : 0.0f;
+    f3 specular = reflect3(din, g.n);
+    specular = norm3(mix3(specular, diffuse, m.roughness));
+    skip_pdf = (doSpecular == 1.0f);
+    return norm3(mix3(diffuse, specular, doSpecular));
+  } else if (bin == BIN_MIRROR) {
+    f3 reflected = reflect3(din, g.n);
+    return norm3(reflected + m.roughness * uniform_random_in_unit_sphere(rng));
+  } else if (bin == BIN_GLASS) {
+    float ir = m.eta;
+    if (g.front) ir = (1.0f / ir);
+    f3 ud = norm3(din);
+    float cos_theta = ptm_min(dot3(-ud, g.n), 1.0f);
+    float sin_theta = ptm_sqrt(1.0f - cos_theta * cos_theta);
+    f3 dir;
+    if (ir * sin_theta > 1.0f || reflectance(cos_theta, ir) > rand2D(rng)) {
+      dir = reflect3(ud, g.n);
+    } else {
+      dir = refract3(ud, g.n, ir);
+    }
+    return norm3(dir);
+  } else if (bin == BIN_ISOTROPIC) {
+    float gg = m.specularStrength;
+    float cos_hg = (1.0f + gg * gg - ptm_pow(((1.0f - gg * gg) / (1.0f - gg + 2.0f * gg * rand2D(rng))), 2.0f)) / (2.0f * gg);
+    float sin_hg = ptm_sqrt(1.0f - cos_hg * cos_hg);
+    float phi = kTwoPi * rand2D(rng);
+    f3 hg = mk3(sin_hg * ptm_cos(phi), sin_hg * ptm_sin(phi), cos_hg);
+    Onb b = onb_build_from_w(din);
+    unit_w = b.w;
+    return norm3(onb_get_local(b, hg));
+  }
+  // unknown material_type: `scattered` stays Ray(0,0) (scatterRay.wgsl:4); the caller substitutes a
+  // zero origin too.  skip_pdf would be stale private state in the shader: IS mode rejects such scenes.
+  skip_pdf = false;
+  return mk3(0, 0, 0);
+}
+
+DEV int lane_id() { return (int)(threadIdx.x & 63); }
+DEV uint32_t lanes_below(uint64_t mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+// One atomicAdd per wave for all lanes with pred set; returns each such lane's slot.
+DEV uint32_t wave_append(uint32_t* counter, bool pred) {
+  uint64_t m = __ballot(pred);
+  if (m == 0) return 0;
+  int leader = __ffsll((unsigned long long)m) - 1;
+  uint32_t base = 0;
+  if (lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+  base = (uint32_t)__shfl((int)base, leader, 64);
+  return base + lanes_below(m);
+}
+
+}  // namespace ptmi

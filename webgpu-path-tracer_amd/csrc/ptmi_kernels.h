@@ -1,0 +1,357 @@
+// ptmi_kernels.h — the wavefront integrator's kernels (gfx950).
+//
+//   k_generate   one thread per (frame slot, owned pixel): seeds the RNG (main.wgsl:16), builds the
+//                camera ray (shootRay.wgsl), fills step 0's ray queue.
+//   k_intersect  persistent waves, one ray per lane, LDS traversal stacks: hitScene (hitRay.wgsl:1-113).
+//                Writes the closest-hit record and appends the path to the bin of its material class
+//                (one wave-aggregated atomic per bin).
+//   k_shade      walks the bins (wave-uniform material class): ray_color's loop body
+//                (traceRay.wgsl:10-80) + material_scatter + Russian roulette; survivors are compacted
+//                into the next step's ray queue, finished samples fold into the pixel colour.
+//   k_accumulate framebuffer read-modify-write of main.wgsl:22-27 for every frame slot, in frame order.
+#pragma once
+#include "ptmi_device.h"
+
+namespace ptmi {
+
+constexpr int kBlock = 256;
+
+__global__ __launch_bounds__(kBlock) void k_generate(RenderConst rc, Paths P, uint32_t* __restrict__ q0, StepCtl* __restrict__ ctl) {
+  uint32_t total = rc.n_local * (uint32_t)rc.n_frames;
+  for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < total; g += gridDim.x * kBlock) {
+    uint32_t f = g / rc.n_local, j = g - f * rc.n_local;
+    uint32_t pix = local_to_pixel(rc, j);
+    uint32_t pid = f * rc.npix + pix;
+    // u32(uniforms.frameNum): the frame number travels through an f32 uniform (renderer.js:173)
+    uint32_t rng = pix + (uint32_t)(float)(rc.frame0 + f) * 719393u;
+    f3 o, d;
+    camera_ray(rc, pix, 0, rng, o, d);
+    P.ray[2 * (size_t)pid] = make_float4(o.x, o.y, o.z, 0.0f);
+    P.ray[2 * (size_t)pid + 1] = make_float4(d.x, d.y, d.z, 0.0f);
+    P.thr[pid] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0));
+    P.acc[pid] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(0));
+    if (P.pixsum) P.pixsum[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    P.rng[pid] = rng;
+    q0[g] = pid;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) ctl[0].n_rays = total;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, Paths P, StepCtl* __restrict__ ctl, const uint32_t* __restrict__ q_in,
+                                                      uint32_t* __restrict__ q_bins, uint32_t cap, int stack_size, int stack_alloc,
+                                                      unsigned long long* __restrict__ totals) {
+  extern __shared__ int lds_stack[];
+  const int lane = lane_id();
+  int* stk = lds_stack + (threadIdx.x >> 6) * (stack_alloc * 64) + lane;
+  const uint32_t n = ctl->n_rays;
+  Counters cn = {0, 0, 0, 0, 0};
+
+  while (true) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&ctl->head, 64u);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (base >= n) break;
+    uint32_t i = base + lane;
+    bool active = i < n;
+    int bin = -1;
+    uint32_t pid = 0;
+    if (active) {
+      pid = q_in[i];
+      float4 r0 = P.ray[2 * (size_t)pid], r1 = P.ray[2 * (size_t)pid + 1];
+      f3 o = mk3(r0), d = mk3(r1);
+      Closest c;
+      c.t = kMaxFloat;
+      c.u = c.v = 0.0f;
+      c.prim = K_NONE;
+      c.mat = 0;
+      if (S.n_spheres > 0) {
+        uint32_t rng = P.rng[pid];
+        uint32_t rng0 = rng;
+        hit_spheres<COUNT>(S, o, d, rng, c, cn);
+        if (rng != rng0) P.rng[pid] = rng;
+      }
+      hit_quads<COUNT>(S, o, d, c, cn);
+      traverse_bvh<COUNT>(S, o, d, stack_size, stk, c, cn);
+      P.hit[pid] = make_float4(c.t, c.u, c.v, __uint_as_float(c.prim));
+      if ((c.prim >> 28) == K_NONE) {
+        bin = BIN_MISS;
+      } else {
+        P.hitmat[pid] = (uint32_t)c.mat;
+        float ty = S.mats[4 * c.mat + 3].z;
+        bin = (ty == 0.0f) ? BIN_LAMBERTIAN : (ty == 1.0f) ? BIN_MIRROR : (ty == 2.0f) ? BIN_GLASS : (ty == 3.0f) ? BIN_ISOTROPIC : BIN_OTHER;
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NUM_BINS; b++) {
+      bool mine = (bin == b);
+      uint32_t slot = wave_append(&ctl->bin_n[b], mine);
+      if (mine) q_bins[(size_t)b * cap + slot] = pid;
+    }
+  }
+
+  if (COUNT) {
+    // wave reduction, then one atomic per counter per wave
+    uint32_t v[5] = {cn.node_visits, cn.tri_tests, cn.sphere_tests, cn.quad_tests, cn.mat_fetches};
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      unsigned long long x = v[k];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+      if (lane == 0 && x) atomicAdd(&totals[2 + k], x);
+    }
+  }
+}
+
+// One path's iteration of the `for i < MAX_BOUNCES` loop body after hitScene (traceRay.wgsl:10-80).
+// Returns true when the path continues with a new ray (already stored), false when this slot is done.
+template <bool IS>
+DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, int bin, uint32_t pid, const QuadL& L) {
+  float4 r0 = P.ray[2 * (size_t)pid], r1 = P.ray[2 * (size_t)pid + 1];
+  f3 o = mk3(r0), d = mk3(r1);
+  float4 T4 = P.thr[pid], A4 = P.acc[pid];
+  f3 T = mk3(T4), acc = mk3(A4);
+  int bounce = __float_as_int(T4.w), sample = __float_as_int(A4.w);
+  uint32_t rng = P.rng[pid];
+
+  bool sample_done = false;
+  f3 radiance = acc;
+  f3 no = o, nd = d;
+
+  if (bin == BIN_MISS) {  // traceRay.wgsl:12-16
+    radiance = acc + (mk3(rc.bg[0], rc.bg[1], rc.bg[2]) * T);
+    sample_done = true;
+  } else {
+    float4 h = P.hit[pid];
+    int mat = (int)P.hitmat[pid];
+    Material m = load_material(S, mat);
+    HitGeom g = resolve_hit(S, o, d, h.x, h.y, h.z, __float_as_uint(h.w));
+    f3 emission = m.emission;
+    if (!g.front) emission = mk3(0, 0, 0);  // traceRay.wgsl:19-22
+    float doSpecular;
+    bool skip_pdf;
+    f3 unit_w = mk3(0, 0, 0);
+    f3 sdir = material_scatter(bin, m, g, d, rng, doSpecular, skip_pdf, unit_w);
+    f3 sorg = (bin == BIN_OTHER) ? mk3(0, 0, 0) : g.p;
+    bool roulette = true;
+    if (IS) {  // traceRay.wgsl:24-58
+      if (skip_pdf) {
+        acc = acc + emission * T;
+        T = T * mix3(m.color, m.spec, doSpecular);
+        no = sorg;
+        nd = sdir;
+        roulette = false;  // `continue` skips the Russian roulette
+      } else {
+        // get_random_on_quad(lights, hitRec.p) (importanceSampling.wgsl:78-81): u draw, then v draw
+        float ru = rand2D(rng);
+        f3 pu = ru * L.u;
+        float rv = rand2D(rng);
+        f3 pv = rv * L.v;
+        f3 lp = L.Q + pu + pv;
+        f3 ldir = norm3(lp - g.p);
+        f3 so = g.p, sd = ldir;
+        float rnd = rand2D(rng);
+        if (rnd > 0.2f) {
+          so = sorg;
+          sd = sdir;
+        }
+        float cosine_theta = dot3(norm3(sd), unit_w);  // onb_lambertian_scattering_pdf :73-76
+        float lambertian_pdf = ptm_max(0.0f, cosine_theta / kPi);
+        float lpdf = light_pdf(L, so, sd);
+        float pdf = 0.2f * lpdf + 0.8f * lambertian_pdf;
+        if (pdf <= 0.00001f) {  // returns emission*throughput, dropping acc (Q8)
+          radiance = emission * T;
+          sample_done = true;
+        } else {
+          acc = acc + emission * T;
+          T = T * ((lambertian_pdf * mix3(m.color, m.spec, doSpecular)) / pdf);
+          no = so;
+          nd = sd;
+        }
+      }
+    } else {  // traceRay.wgsl:61-68
+      acc = acc + emission * T;
+      T = T * mix3(m.color, m.spec, doSpecular);
+      no = sorg;
+      nd = sdir;
+    }
+    if (!sample_done) {
+      if (roulette && bounce > 2) {  // traceRay.wgsl:71-79
+        float p = ptm_max(T.x, ptm_max(T.y, T.z));
+        if (rand2D(rng) > p) {
+          sample_done = true;
+        } else {
+          T = T * (1.0f / p);
+        }
+      }
+      if (!sample_done) {
+        bounce++;
+        if (bounce >= rc.max_bounces) sample_done = true;  // loop exhausted: returns acc (Q8)
+      }
+      radiance = acc;
+    }
+  }
+
+  if (!sample_done) {
+    P.ray[2 * (size_t)pid] = make_float4(no.x, no.y, no.z, 0.0f);
+    P.ray[2 * (size_t)pid + 1] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+    P.thr[pid] = make_float4(T.x, T.y, T.z, __int_as_float(bounce));
+    P.acc[pid] = make_float4(acc.x, acc.y, acc.z, __int_as_float(sample));
+    P.rng[pid] = rng;
+    return true;
+  }
+
+  // pathTrace (shootRay.wgsl:5-49): pixColor += ray_color(ray); next sample continues the same RNG stream
+  f3 sum = radiance;
+  if (rc.num_samples > 1) {
+    sum = mk3(P.pixsum[pid]) + radiance;
+  } else {
+    sum = mk3(0, 0, 0) + radiance;
+  }
+  sample++;
+  if (sample < rc.num_samples) {
+    P.pixsum[pid] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+    uint32_t pix = pid % rc.npix;
+    camera_ray(rc, pix, sample, rng, no, nd);
+    P.ray[2 * (size_t)pid] = make_float4(no.x, no.y, no.z, 0.0f);
+    P.ray[2 * (size_t)pid + 1] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+    P.thr[pid] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0));
+    P.acc[pid] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(sample));
+    P.rng[pid] = rng;
+    return true;
+  }
+  f3 fin = sum / rc.sample_div;
+  P.acc[pid] = make_float4(fin.x, fin.y, fin.z, __int_as_float(sample));
+  return false;
+}
+
+template <bool IS>
+__global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl,
+                                                  const uint32_t* __restrict__ q_bins, uint32_t cap, uint32_t* __restrict__ q_next) {
+  const QuadL L = load_light(S);
+  const uint32_t wave_stride = gridDim.x * kBlock;
+  const uint32_t wave_base = (blockIdx.x * kBlock + threadIdx.x) & ~63u;
+  const int lane = lane_id();
+#pragma unroll 1
+  for (int b = 0; b < NUM_BINS; b++) {
+    const uint32_t n = ctl->bin_n[b];
+    const uint32_t* q = q_bins + (size_t)b * cap;
+    for (uint32_t base = wave_base; base < n; base += wave_stride) {
+      uint32_t i = base + lane;
+      bool active = i < n;
+      bool survive = false;
+      uint32_t pid = 0;
+      if (active) {
+        pid = q[i];
+        survive = shade_one<IS>(S, rc, P, b, pid, L);
+      }
+      uint32_t slot = wave_append(&ctl[1].n_rays, survive);
+      if (survive) q_next[slot] = pid;
+    }
+  }
+}
+
+// main.wgsl:22-27 for all frame slots of the batch, in frame order; also tallies rays/paths.
+__global__ __launch_bounds__(kBlock) void k_accumulate(RenderConst rc, Paths P, float4* __restrict__ fb, const StepCtl* __restrict__ ctl, int n_steps,
+                                                       unsigned long long* __restrict__ totals) {
+  for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < rc.n_local; j += gridDim.x * kBlock) {
+    uint32_t pix = local_to_pixel(rc, j);
+    float4 cur = fb[pix];
+    f3 c = mk3(cur);
+    for (int f = 0; f < rc.n_frames; f++) {
+      float4 a = P.acc[(size_t)f * rc.npix + pix];
+      f3 col = mk3(a);
+      if (f == 0 && rc.reset_first) {
+        c = col;
+      } else {
+        c = c + col;
+      }
+    }
+    fb[pix] = make_float4(c.x, c.y, c.z, 1.0f);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    unsigned long long rays = 0;
+    for (int s = 0; s < n_steps; s++) rays += ctl[s].n_rays;
+    totals[0] += rays;
+    totals[1] += (unsigned long long)rc.n_local * (unsigned long long)rc.n_frames * (unsigned long long)rc.num_samples;
+  }
+}
+
+// ---- test hooks ------------------------------------------------------------------------------------
+struct HitOut {
+  int32_t hit;
+  float t;
+  float p[3];
+  float normal[3];
+  int32_t front_face;
+  float material[16];
+};
+
+__global__ __launch_bounds__(kBlock) void k_resolve_hits(DevScene S, Paths P, uint32_t n, HitOut* __restrict__ out) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  float4 h = P.hit[i];
+  uint32_t prim = __float_as_uint(h.w);
+  HitOut o;
+  for (int k = 0; k < 16; k++) o.material[k] = 0.0f;
+  o.t = 0.0f;
+  o.p[0] = o.p[1] = o.p[2] = o.normal[0] = o.normal[1] = o.normal[2] = 0.0f;
+  o.front_face = 0;
+  o.hit = (prim >> 28) != K_NONE;
+  if (o.hit) {
+    float4 r0 = P.ray[2 * (size_t)i], r1 = P.ray[2 * (size_t)i + 1];
+    HitGeom g = resolve_hit(S, mk3(r0), mk3(r1), h.x, h.y, h.z, prim);
+    o.t = h.x;
+    o.p[0] = g.p.x, o.p[1] = g.p.y, o.p[2] = g.p.z;
+    o.normal[0] = g.n.x, o.normal[1] = g.n.y, o.normal[2] = g.n.z;
+    o.front_face = g.front ? 1 : 0;
+    const float4* m = S.mats + 4 * P.hitmat[i];
+    for (int k = 0; k < 4; k++) {
+      float4 v = m[k];
+      o.material[4 * k] = v.x, o.material[4 * k + 1] = v.y, o.material[4 * k + 2] = v.z, o.material[4 * k + 3] = v.w;
+    }
+  }
+  out[i] = o;
+}
+
+__global__ void k_math_eval(int fn, size_t n, const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a = x[i], b = y ? y[i] : 0.0f, r = 0.0f;
+  switch (fn) {
+    case 0: r = ptm_sin(a); break;
+    case 1: r = ptm_cos(a); break;
+    case 2: r = ptm_acos(a); break;
+    case 3: r = ptm_log(a); break;
+    case 4: r = ptm_log2(a); break;
+    case 5: r = ptm_exp2(a); break;
+    case 6: r = ptm_pow(a, b); break;
+    case 7: r = ptm_sqrt(a); break;
+    case 8: r = ptm_min(a, b); break;
+    case 9: r = ptm_max(a, b); break;
+    case 10: r = a / b; break;
+  }
+  out[i] = r;
+}
+
+// shaders/fragment.js:22-36 + shaders/common.wgsl:273-282: colour = fb/frameNum -> ACES approx -> gamma
+__global__ __launch_bounds__(kBlock) void k_resolve_rgba8(const float4* __restrict__ fb, uint32_t npix, float frame_num, uchar4* __restrict__ out) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= npix) return;
+  float4 c = fb[i];
+  float v[3] = {c.x / frame_num, c.y / frame_num, c.z / frame_num};
+  unsigned char q[3];
+  const float inv_gamma = 1 / 2.2;
+  for (int k = 0; k < 3; k++) {
+    float v1 = v[k] * 0.6f;
+    float a = (v1 * (2.51f * v1 + 0.03f)) / (v1 * (2.43f * v1 + 0.59f) + 0.14f);
+    a = ptm_min(ptm_max(a, 0.0f), 1.0f);
+    float g = ptm_pow(a, inv_gamma);
+    // canvas store: unorm8 round-to-nearest
+    float s = g * 255.0f + 0.5f;
+    s = ptm_min(ptm_max(s, 0.0f), 255.0f);
+    q[k] = (unsigned char)s;
+  }
+  out[i] = make_uchar4(q[0], q[1], q[2], 255);
+}
+
+}  // namespace ptmi

@@ -1,0 +1,264 @@
+"""ctypes binding of include/ptmi.h (libptmi.so).  No fallbacks: if the library is missing or a call
+fails, this raises — there is no CPU path in the product."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _build
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+BUF = {"spheres": 1, "quads": 2, "triangles": 5, "meshes": 6, "transforms": 7, "materials": 8, "bvh": 9}
+
+# every symbol include/ptmi.h declares
+SYMBOLS = [
+    "ptmi_version", "ptmi_status_string", "ptmi_last_error", "ptmi_create", "ptmi_destroy", "ptmi_default_params",
+    "ptmi_set_params", "ptmi_get_params", "ptmi_upload", "ptmi_resize", "ptmi_clear_framebuffer", "ptmi_set_shard",
+    "ptmi_render_frame", "ptmi_render", "ptmi_synchronize", "ptmi_read_framebuffer", "ptmi_write_framebuffer",
+    "ptmi_framebuffer_device_ptr", "ptmi_bind_framebuffer", "ptmi_stream", "ptmi_resolve_rgba8", "ptmi_set_counters",
+    "ptmi_set_timing", "ptmi_get_stats", "ptmi_reset_stats", "ptmi_trace", "ptmi_math_eval", "ptmi_build_bvh",
+]
+
+
+class Params(ctypes.Structure):
+    _fields_ = [
+        ("num_samples", ctypes.c_int32), ("max_bounces", ctypes.c_int32), ("stratify", ctypes.c_int32),
+        ("importance_sampling", ctypes.c_int32), ("stack_size", ctypes.c_int32), ("background", ctypes.c_float * 3),
+        ("fov_degrees", ctypes.c_float), ("frames_in_flight", ctypes.c_int32), ("reserved", ctypes.c_int32 * 5),
+    ]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in (
+        "rays", "paths", "node_visits", "tri_tests", "sphere_tests", "quad_tests", "mat_fetches", "frames",
+        "intersect_launches", "shade_launches")] + [(n, ctypes.c_double) for n in ("render_ms", "intersect_ms", "shade_ms", "other_ms")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+HIT_DTYPE = np.dtype([("hit", "<i4"), ("t", "<f4"), ("p", "<f4", 3), ("normal", "<f4", 3), ("front_face", "<i4"), ("material", "<f4", 16)])
+
+
+class PtmiError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("ptmi status %d: %s" % (status, message))
+        self.status = status
+
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load_library(build=False):
+    """dlopen libptmi.so (optionally building it first).  Raises if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build:
+        _build.build_lib()
+    if not os.path.exists(_build.LIB):
+        raise OSError("libptmi.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc)")
+    L = ctypes.CDLL(_build.LIB)
+    vp, i32, u32, sz, fp = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_size_t, ctypes.c_void_p
+    L.ptmi_version.restype = i32
+    L.ptmi_status_string.restype = ctypes.c_char_p
+    L.ptmi_status_string.argtypes = [i32]
+    L.ptmi_last_error.restype = ctypes.c_char_p
+    L.ptmi_last_error.argtypes = [vp]
+    L.ptmi_create.argtypes = [ctypes.POINTER(vp), i32]
+    L.ptmi_destroy.argtypes = [vp]
+    L.ptmi_destroy.restype = None
+    L.ptmi_default_params.argtypes = [ctypes.POINTER(Params)]
+    L.ptmi_default_params.restype = None
+    L.ptmi_set_params.argtypes = [vp, ctypes.POINTER(Params)]
+    L.ptmi_get_params.argtypes = [vp, ctypes.POINTER(Params)]
+    L.ptmi_upload.argtypes = [vp, i32, fp, sz]
+    L.ptmi_resize.argtypes = [vp, i32, i32]
+    L.ptmi_clear_framebuffer.argtypes = [vp]
+    L.ptmi_set_shard.argtypes = [vp, i32, i32, i32]
+    L.ptmi_render_frame.argtypes = [vp, fp]
+    L.ptmi_render.argtypes = [vp, fp, u32, u32]
+    L.ptmi_synchronize.argtypes = [vp]
+    L.ptmi_read_framebuffer.argtypes = [vp, fp, sz]
+    L.ptmi_write_framebuffer.argtypes = [vp, fp, sz]
+    L.ptmi_framebuffer_device_ptr.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(sz)]
+    L.ptmi_bind_framebuffer.argtypes = [vp, vp, sz]
+    L.ptmi_stream.argtypes = [vp, ctypes.POINTER(vp)]
+    L.ptmi_resolve_rgba8.argtypes = [vp, ctypes.c_float, fp, sz]
+    L.ptmi_set_counters.argtypes = [vp, i32]
+    L.ptmi_set_timing.argtypes = [vp, i32]
+    L.ptmi_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+    L.ptmi_reset_stats.argtypes = [vp]
+    L.ptmi_trace.argtypes = [vp, sz, fp, fp, fp]
+    L.ptmi_math_eval.argtypes = [vp, i32, sz, fp, fp, fp]
+    L.ptmi_build_bvh.argtypes = [sz, fp, fp, i32, fp, fp]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def default_params(**kw):
+    p = Params()
+    load_library().ptmi_default_params(ctypes.byref(p))
+    for k, v in kw.items():
+        if k == "background":
+            p.background[:] = list(v)
+        else:
+            setattr(p, k, v)
+    return p
+
+
+class NativeHost:
+    """Host-side natives (no GPU): plug into host.scene.build_bvh(native=...)."""
+
+    def __init__(self):
+        self.lib = load_library()
+
+    def build_bvh(self, bmin, bmax, prim_type=2):
+        bmin = np.ascontiguousarray(bmin, np.float64)
+        bmax = np.ascontiguousarray(bmax, np.float64)
+        n = bmin.shape[0]
+        nodes = np.zeros((max(2 * n - 1, 0), 12), np.float32)
+        order = np.zeros(n, np.int64)
+        st = self.lib.ptmi_build_bvh(n, _ptr(bmin), _ptr(bmax), prim_type, _ptr(nodes), _ptr(order))
+        if st != 0:
+            raise PtmiError(st, "ptmi_build_bvh failed")
+        return nodes, order
+
+
+class Context:
+    """One integrator context on one GPU (mirrors the reference's Renderer+WebGPU pair for the hot path)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        st = self.lib.ptmi_create(ctypes.byref(h), device)
+        if st != 0:
+            raise PtmiError(st, self.lib.ptmi_last_error(None).decode())
+        self.h = h
+        self.width = self.height = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ptmi_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, st):
+        if st != 0:
+            raise PtmiError(st, self.lib.ptmi_last_error(self.h).decode())
+
+    def set_params(self, params=None, **kw):
+        p = params if params is not None else default_params(**kw)
+        self._ck(self.lib.ptmi_set_params(self.h, ctypes.byref(p)))
+        return p
+
+    def get_params(self):
+        p = Params()
+        self._ck(self.lib.ptmi_get_params(self.h, ctypes.byref(p)))
+        return p
+
+    def upload(self, which, array):
+        a = np.ascontiguousarray(array)
+        if a.dtype not in (np.float32, np.int32):
+            raise TypeError("buffers are float32 (int32 for meshes)")
+        self._ck(self.lib.ptmi_upload(self.h, BUF[which] if isinstance(which, str) else which, _ptr(a), a.nbytes))
+
+    def upload_scene(self, buffers):
+        for k in ("spheres", "quads", "triangles", "meshes", "transforms", "materials", "bvh"):
+            a = buffers[k]
+            self.upload(k, np.asarray(a, np.int32 if k == "meshes" else np.float32))
+
+    def resize(self, w, h):
+        self._ck(self.lib.ptmi_resize(self.h, w, h))
+        self.width, self.height = w, h
+
+    def clear(self):
+        self._ck(self.lib.ptmi_clear_framebuffer(self.h))
+
+    def set_shard(self, rank, world, tile=64):
+        self._ck(self.lib.ptmi_set_shard(self.h, rank, world, tile))
+
+    def render_frame(self, uniforms20):
+        u = np.ascontiguousarray(uniforms20, np.float32)
+        assert u.size == 20
+        self._ck(self.lib.ptmi_render_frame(self.h, _ptr(u)))
+
+    def render(self, view16, first_frame, n_frames):
+        v = np.ascontiguousarray(view16, np.float32)
+        assert v.size == 16
+        self._ck(self.lib.ptmi_render(self.h, _ptr(v), first_frame, n_frames))
+
+    def synchronize(self):
+        self._ck(self.lib.ptmi_synchronize(self.h))
+
+    def read_framebuffer(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._ck(self.lib.ptmi_read_framebuffer(self.h, _ptr(out), out.nbytes))
+        return out
+
+    def write_framebuffer(self, fb):
+        a = np.ascontiguousarray(fb, np.float32)
+        self._ck(self.lib.ptmi_write_framebuffer(self.h, _ptr(a), a.nbytes))
+
+    def framebuffer_device_ptr(self):
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        self._ck(self.lib.ptmi_framebuffer_device_ptr(self.h, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def bind_framebuffer(self, dev_ptr, nbytes):
+        self._ck(self.lib.ptmi_bind_framebuffer(self.h, ctypes.c_void_p(dev_ptr), nbytes))
+
+    def stream(self):
+        p = ctypes.c_void_p()
+        self._ck(self.lib.ptmi_stream(self.h, ctypes.byref(p)))
+        return p.value
+
+    def resolve_rgba8(self, frame_num):
+        out = np.empty((self.height, self.width, 4), np.uint8)
+        self._ck(self.lib.ptmi_resolve_rgba8(self.h, float(frame_num), _ptr(out), out.nbytes))
+        return out
+
+    def set_counters(self, on):
+        self._ck(self.lib.ptmi_set_counters(self.h, int(on)))
+
+    def set_timing(self, on):
+        self._ck(self.lib.ptmi_set_timing(self.h, int(on)))
+
+    def stats(self):
+        s = Stats()
+        self._ck(self.lib.ptmi_get_stats(self.h, ctypes.byref(s)))
+        return s.as_dict()
+
+    def reset_stats(self):
+        self._ck(self.lib.ptmi_reset_stats(self.h))
+
+    def trace(self, rays6, rng=None):
+        r = np.ascontiguousarray(rays6, np.float32).reshape(-1, 6)
+        n = r.shape[0]
+        out = np.zeros(n, HIT_DTYPE)
+        g = None if rng is None else np.ascontiguousarray(rng, np.uint32).copy()
+        self._ck(self.lib.ptmi_trace(self.h, n, _ptr(r), None if g is None else _ptr(g), _ptr(out)))
+        return out, g
+
+    def math_eval(self, fn, x, y=None):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty_like(x)
+        yy = None if y is None else np.ascontiguousarray(y, np.float32)
+        self._ck(self.lib.ptmi_math_eval(self.h, fn, x.size, _ptr(x), None if yy is None else _ptr(yy), _ptr(out)))
+        return out

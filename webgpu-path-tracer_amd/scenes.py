@@ -1,0 +1,181 @@
+"""Canonical scenes built through the Scene API, plus golden-buffer loading.
+
+``default``  the reference scene exactly as lib/scene.js ships it (19 spheres, 8 quads, rotated cube)
+``c1``       Cornell box + mirror sphere + glass sphere, no triangles           (BASELINE configs[0])
+``c2``       Cornell box + monkey_968.obj, scale 0.6, translate (0,-0.4,0)      (BASELINE configs[1])
+``c2m``      Cornell box + 2 meshes + fog/glass sphere pair (multi-mesh / volume coverage)
+"""
+import json
+import math
+import os
+
+import numpy as np
+
+from .host.scene import Camera, ObjReader, Scene
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+BUFFER_NAMES = ("spheres", "quads", "triangles", "meshes", "transforms", "materials", "bvh")
+
+
+def _cornell_materials(sc):  # lib/scene.js:107-113
+    sc.add_material("red", 0, [0.75, 0.1, 0.1], [0.75, 0.1, 0.1], [0, 0, 0], 0.05, 0.95, 0)
+    sc.add_material("green", 0, [0.05, 0.55, 0.05], [0.05, 0.55, 0.05], [0, 0, 0], 0.05, 0.95, 0)
+    sc.add_material("blue", 0, [0.05, 0.05, 0.55], [0.05, 0.05, 0.55], [0, 0, 0], 0.05, 0.95, 0)
+    sc.add_material("white", 0, [0.76, 0.70, 0.51], [0.76, 0.70, 0.51], [0, 0, 0], 0.05, 0.95, 0)
+    sc.add_material("glossywhite", 0, [0.76, 0.70, 0.51], [0.76, 0.70, 0.51], [0, 0, 0], 0.3, 0.1, 0)
+    sc.add_material("black", 0, [0.2, 0.2, 0.2], [0.2, 0.2, 0.2], [0, 0, 0], 0.05, 0.95, 0)
+    sc.add_material("glass", 1, [0.95, 0.95, 0.95], [0, 0, 0], [0, 0, 0], 0, 0, 0)
+
+
+def _cornell_quads(sc):  # walls of lib/scene.js:128-132 + the light of SURVEY.md §8d-C1
+    _cornell_materials(sc)
+    d = sc.material_dict
+    sc.add_quad([-0.35, 0.9999, -0.3], [0.7, 0, 0], [0, 0, 0.6], sc.add_material("light", 0, [0, 0, 0], [0, 0, 0], [10, 10, 10], 0, 0, 0))
+    sc.add_quad([-1, -1, -1], [2, 0, 0], [0, 2, 0], d["black"])
+    sc.add_quad([-1, -1, 1], [0, 0, -2], [0, 2, 0], d["red"])
+    sc.add_quad([1, -1, -1], [0, 0, 2], [0, 2, 0], d["green"])
+    sc.add_quad([-1, 1, -1], [2, 0, 0], [0, 0, 2], d["white"])
+    sc.add_quad([1, -1, -1], [-2, 0, 0], [0, 0, 2], d["glossywhite"])
+    sc.lights.append(sc.quads[0])
+    sc.objs.extend(sc.quads)
+
+
+class CornellScene(Scene):
+    """Cornell walls + light; spheres and meshes supplied by callables."""
+
+    def __init__(self, spheres=None, meshes=None):
+        self._spheres_fn, self._meshes_fn = spheres, meshes
+        super().__init__()
+
+    def create_spheres(self):
+        self.add_material("default", 0, [1, 0, 0], [0, 0, 0], [0, 0, 0], 0, 0, 0)
+        if self._spheres_fn:
+            self._spheres_fn(self)
+        self.objs.extend(self.spheres)
+
+    def create_quads(self):
+        _cornell_quads(self)
+
+    def create_meshes(self):
+        if self._meshes_fn:
+            self._meshes_fn(self)
+        self._finish_meshes()
+
+
+def c1_scene():
+    def spheres(sc):
+        sc.add_sphere([-0.5, -0.7, -0.5], 0.3, sc.add_material("mirror_ball", 1, [0.95, 0.95, 0.95], [0.95, 0.95, 0.95], [0, 0, 0], 0, 0, 0))
+        sc.add_sphere([0.6, -0.75, 0.5], 0.25, sc.add_material("glass_ball", 2, [1, 1, 1], [0, 0, 0], [0, 0, 0], 0, 0, 1.5))
+
+    return CornellScene(spheres=spheres)
+
+
+DRAGON_MAT = ("dragonMat", 0, [0.0, 0.37, 0.20], [0.0, 0.95, 0.95], [0, 0, 0], 0.4, 0.3, 2.5)  # lib/scene.js:166
+
+
+def mesh_scene(mesh_data, scale=(1, 1, 1), rotate=None, translate=(0, 0, 0), material=DRAGON_MAT):
+    """Cornell box + one mesh with scale -> rotate -> translate (the order of lib/scene.js:216-220)."""
+
+    def meshes(sc):
+        m = sc.add_mesh(mesh_data, sc.add_material(*material))
+        ops = [m.transform.scale(*scale)]
+        if rotate is not None:
+            ops.append(m.transform.rotate(rotate[0], rotate[1]))
+        ops.append(m.transform.translate(*translate))
+        m.transform.update(*ops)
+
+    return CornellScene(meshes=meshes)
+
+
+def c2_scene(monkey_data):
+    def meshes(sc):
+        m = sc.add_mesh(monkey_data, sc.add_material(*DRAGON_MAT))
+        m.transform.update(m.transform.scale(0.6, 0.6, 0.6), m.transform.translate(0, -0.4, 0))
+
+    return CornellScene(meshes=meshes)
+
+
+def c2m_scene(ico_data, cube_data):
+    def spheres(sc):
+        sc.add_sphere([-0.45, -0.6, 0.45], 0.3, sc.add_material("fog", 3, [0.56, 0.93, 0.56], [0, 0, 0], [0, 0, 0], 0.00001, -1 / 4, 0))
+        sc.add_sphere([-0.45, -0.6, 0.45], 0.3, sc.add_material("gg4t", 2, [1, 1, 1], [0, 0, 0], [0, 0, 0], 0, 0, 1.5))
+
+    def meshes(sc):
+        a = sc.add_mesh(ico_data, sc.add_material(*DRAGON_MAT))
+        b = sc.add_mesh(cube_data, sc.add_material("box2", 1, [0.95, 0.95, 0.95], [0.95, 0.95, 0.95], [0, 0, 0], 0, 0.05, 1.5))
+        a.transform.update(a.transform.scale(0.35, 0.35, 0.35), a.transform.rotate(math.pi / 4, [0, 1, 0]), a.transform.translate(0.45, -0.64, 0))
+        b.transform.update(b.transform.scale(0.2, 0.3, 0.2), b.transform.rotate(-math.pi / 4, [1, 1, 0]), b.transform.translate(-0.1, -0.55, -0.4))
+
+    return CornellScene(spheres=spheres, meshes=meshes)
+
+
+class DefaultScene(Scene):
+    """lib/scene.js:36-251 as shipped."""
+
+    def __init__(self, cube_data):
+        self._cube = cube_data
+        super().__init__()
+
+    def create_spheres(self):  # lib/scene.js:36-103
+        self.add_material("default", 0, [1, 0, 0], [0, 0, 0], [0, 0, 0], 0, 0, 0)
+        temp = [0.94, 0.70, 0.75]
+        green = [0.56, 0.93, 0.56]
+
+        def pair(c, r, fog_col, density, eta):
+            self.add_sphere(c, r, self.add_material("fog", 3, fog_col, [0, 0, 0], [0, 0, 0], 0.00001, density, 0))
+            self.add_sphere(c, r, self.add_material("gg4t", 2, [1, 1, 1], [0, 0, 0], [0, 0, 0], 0, 0, eta))
+
+        for c, r in (([-0.3, -0.65, 0.3], 0.35), ([-0.3, -0.05, 0.3], 0.25), ([-0.3, 0.3, 0.3], 0.1), ([-0.3, 0.45, 0.3], 0.05)):
+            pair(c, r, green, -1 / 4, 1.5)
+        pair([0.5, -0.65, -0.2], 0.35, [0.52, 0.8, 0.92], -1 / 7, 1)
+        self.add_sphere([0.5, 0.1, 0.2], 0.2, self.add_material("gg4t", 2, [1, 1, 1], [0, 0, 0], [0, 0, 0], 0, 0, 1.5))
+        for c, r in (([1.3, -0.65, 0.3], 0.35), ([1.3, -0.05, 0.3], 0.25), ([1.3, 0.3, 0.3], 0.1), ([1.3, 0.45, 0.3], 0.05)):
+            pair(c, r, temp, -1 / 10, 1)
+        self.objs.extend(self.spheres)
+
+    def create_quads(self):  # lib/scene.js:105-162
+        _cornell_materials(self)
+        d = self.material_dict
+        self.add_quad([-1, 1, -1], [3, 0, 0], [0, 0, 2], self.add_material("tWall", 0, [0, 0, 0], [0, 0, 0], [2, 2, 2], 0, 0))
+        self.add_quad([-1, -1, -1], [3, 0, 0], [0, 2, 0], d["black"])
+        self.add_quad([-1, -1, 1], [0, 0, -2], [0, 2, 0], d["red"])
+        self.add_quad([2, -1, -1], [0, 0, 2], [0, 2, 0], d["green"])
+        self.add_quad([-1, 1, -1], [3, 0, 0], [0, 0, 2], d["white"])
+        self.add_quad([2, -1, -1], [-3, 0, 0], [0, 0, 2], d["glossywhite"])
+        self.add_quad([100, -1, -100], [-200, 0, 0], [0, 0, 200], d["white"])
+        self.add_quad([2, -1, 1], [-3, 0, 0], [0, 2, 0], self.add_material("fWall", 0, [0.15, 0.15, 0.15], [0, 0, 0], [0, 0, 0], 0, 0, 0))
+        self.lights.append(self.quads[0])
+        self.objs.extend(self.quads)
+
+    def create_meshes(self):  # lib/scene.js:164-251
+        self.add_material(*DRAGON_MAT)
+        m = self.add_mesh(self._cube, self.add_material("glassBox", 0, [0.95, 0.95, 0.95], [0, 0, 0], [0, 0, 0], 0, 0, 2.5))
+        m.transform.update(m.transform.rotate(math.pi / 10, [0, 1, 0]))
+        self._finish_meshes()
+
+
+def camera_view(eye, center, up=(0, 1, 0)):
+    cam = Camera()
+    cam.set_camera(list(eye), list(center), list(up))
+    return cam.viewMatrix.copy()
+
+
+CAMERAS = {"default": ([0.5, 0, 2.5], [0.5, 0, 0]), "cornell": ([0, 0, 2.5], [0, 0, 0]), "oblique": ([1.2, 0.4, 2.1], [0.1, -0.2, 0])}
+
+
+def golden_manifest():
+    with open(os.path.join(GOLDEN_DIR, "manifest.json")) as f:
+        return json.load(f)
+
+
+def golden_buffers(name):
+    """Host buffers captured from the reference's own JS (oracle/capture/capture.mjs)."""
+    man = golden_manifest()[name]
+    out = {}
+    for k in BUFFER_NAMES:
+        if k in man and man[k]["stored"]:
+            dt = np.int32 if man[k]["dtype"] == "i32" else np.float32
+            out[k] = np.fromfile(os.path.join(GOLDEN_DIR, f"{name}_{k}.bin"), dtype=dt)
+        else:
+            out[k] = np.zeros(0, np.int32 if k == "meshes" else np.float32)
+    return out
