@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the HIP wavefront integrator on BASELINE.json's configs[1]
+(Cornell + monkey_968.obj, 1920x1080, 64 spp, 8 bounces), one JSON line on rank 0.
+
+A "step" is one full render of the workload: clear the accumulation buffer, trace `spp` progressive
+frames (frame numbers 1..spp, resetBuffer = 0), and — for N > 1 — sum-reduce the per-rank framebuffers
+to rank 0.  Scene, BVH and path buffers are resident in HBM before the timed region.
+Rays are counted exactly (one per hitScene invocation) by the device.
+N > 1 is weak scaling: pixels are sharded across ranks in tiles and spp is multiplied by N, so the
+rays per GPU stay fixed.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def alg_bytes(st):
+    """SURVEY.md §8d algorithmic bytes of hitScene in the reference's layouts."""
+    return 48 * st["node_visits"] + 96 * st["tri_tests"] + 64 * st["mat_fetches"] + 32 * st["sphere_tests"] + 80 * st["quad_tests"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=["c2"])
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=64, help="progressive frames per step and per GPU")
+    ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--frames-in-flight", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+
+    pkg = entry._load_pkg()
+    from webgpu_path_tracer_amd import dist as pdist
+
+    rank, world, local = pdist.init_process_group()
+    if world != max(args.gpus, 1):
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local)
+
+    W, H = args.width, args.height
+    spp = args.spp * world
+    buffers = pkg.scenes.golden_buffers("c2")  # reference-generated buffers of configs[1] (tests/golden)
+    view = pkg.scenes.camera_view(*pkg.scenes.CAMERAS["cornell"])
+    ctx = pkg.Context(local)
+    ctx.upload_scene(buffers)
+    ctx.set_params(max_bounces=args.bounces, frames_in_flight=args.frames_in_flight)
+    ctx.resize(W, H)
+    fb_t = None
+    if world > 1:
+        fb_t = torch.zeros(H * W * 4, dtype=torch.float32, device="cuda")
+        ctx.bind_framebuffer(fb_t.data_ptr(), fb_t.numel() * 4)
+        ctx.set_shard(rank, world, pdist.TILE_PIXELS)
+
+    def step():
+        ctx.clear()
+        ctx.render(view, 1, spp)
+        ctx.synchronize()
+        if world > 1:
+            pdist.reduce_framebuffer(fb_t, 0)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()
+    ctx.reset_stats()
+    ctx.set_timing(True)
+    torch.cuda.synchronize()
+    pdist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    pdist.barrier()
+    dt = time.perf_counter() - t0
+    st = ctx.stats()
+    ctx.set_timing(False)
+
+    dt_max = pdist.all_reduce_scalar(dt, "max")
+    rays_all = pdist.all_reduce_scalar(st["rays"], "sum")
+    paths_all = pdist.all_reduce_scalar(st["paths"], "sum")
+
+    # exact algorithmic bytes of one step (counted variant of the same kernels, untimed)
+    ctx.reset_stats()
+    ctx.set_counters(True)
+    ctx.clear()
+    ctx.render(view, 1, spp)
+    cst = ctx.stats()
+    ctx.set_counters(False)
+    assert cst["rays"] * args.steps == st["rays"], "ray count differs between the counted and the timed pass"
+    bytes_total = alg_bytes(cst) * args.steps
+    launches = max(st["intersect_launches"], 1)
+    isect_s = st["intersect_ms"] / 1e3
+    achieved = bytes_total / isect_s / 1e9 if isect_s > 0 else 0.0
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(prof):
+        try:
+            traffic = json.load(open(prof)).get("k_intersect_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "Mrays/s at 1080p, 8 bounces; achieved HBM GB/s vs roofline",
+            "value": rays_all / dt_max / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[1]: Cornell + monkey_968.obj (967 tris), %dx%d, %d spp per GPU (%d total), %d bounces" % (W, H, args.spp, spp, args.bounces),
+                "rays_per_step": rays_all / args.steps,
+                "mpaths_per_s": paths_all / dt_max / 1e6,
+                "parallelism": "pixel tiles x%d + 1 RCCL reduce" % world if world > 1 else "1 GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_intersect",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": bytes_total / launches,
+                "avg_launch_ms": st["intersect_ms"] / launches,
+                "launches": launches,
+                "kernel_ms": {"intersect": st["intersect_ms"], "shade": st["shade_ms"], "other": st["other_ms"], "render": st["render_ms"]},
+            },
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            from oracle import ptm_oracle
+
+            cores = ptm_oracle.max_threads()
+            t = time.perf_counter()
+            _, ost = ptm_oracle.render(buffers, W, H, view, 1, 1, max_bounces=args.bounces, threads=cores)
+            one = time.perf_counter() - t
+            frames = int(max(1, min(args.spp, args.cpu_seconds / max(one, 1e-3))))
+            t = time.perf_counter()
+            _, ost = ptm_oracle.render(buffers, W, H, view, 1, frames, max_bounces=args.bounces, threads=cores)
+            cdt = time.perf_counter() - t
+            out["cpu_baseline"] = {
+                "value": ost["rays"] / cdt / 1e6,
+                "unit": "Mrays/s",
+                "cores": cores,
+                "kind": "port",
+                "sample": "same scene and camera, %dx%d, frames 1..%d of %d (%d rays), scalar f32 oracle with OpenMP over pixels" % (W, H, frames, args.spp, ost["rays"]),
+            }
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
