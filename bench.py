@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--spp", type=int, default=64, help="progressive frames per step and per GPU")
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--frames-in-flight", type=int, default=0)
+    ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the cpu_baseline (the 1-GPU box's CPU share)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -154,7 +155,7 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             from oracle import ptm_oracle
 
-            cores = ptm_oracle.max_threads()
+            cores = min(ptm_oracle.max_threads(), args.cpu_threads)
             t = time.perf_counter()
             _, ost = ptm_oracle.render(buffers, W, H, view, 1, 1, max_bounces=args.bounces, threads=cores)
             one = time.perf_counter() - t

@@ -71,7 +71,7 @@ struct ptmi_ctx {
 
   size_t path_cap = 0;
   bool pixsum_alloc = false;
-  DBuf d_ray, d_thr, d_acc, d_pixsum, d_rng, d_hit, d_hitmat, d_q0, d_q1, d_bins, d_ctl, d_totals, d_scratch;
+  DBuf d_ray, d_thr, d_acc, d_pixsum, d_rng, d_hit, d_hitmat, d_q0, d_q1, d_ctl, d_totals, d_scratch;
   int ctl_cap = 0;
 
   bool counters = false, timing = false;
@@ -326,7 +326,6 @@ int ensure_paths(ptmi_ctx* c, size_t npaths, int n_ctl, bool need_pixsum) {
     HIP_TRY(c, c->d_hitmat.ensure(npaths * 4));
     HIP_TRY(c, c->d_q0.ensure(npaths * 4));
     HIP_TRY(c, c->d_q1.ensure(npaths * 4));
-    HIP_TRY(c, c->d_bins.ensure(npaths * 4 * NUM_BINS));
     c->path_cap = npaths;
     c->pixsum_alloc = false;
   }
@@ -359,16 +358,20 @@ Paths paths_of(ptmi_ctx* c, bool with_pixsum) {
 
 int stack_alloc_for(const ptmi_ctx* c) { return std::max(1, std::min(c->prm.stack_size, std::max(c->bvh_depth, 1))); }
 
-void launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, const uint32_t* q_in, uint32_t* bins, uint32_t cap, uint32_t max_items) {
+uint32_t chunk_grid(const ptmi_ctx* c, uint32_t max_items, int blocks_per_cu) {
+  uint32_t chunks = (max_items + 255) / 256;  // the kernels shrink chunks to 256 entries for small queues
+  return std::max<uint32_t>(1, std::min<uint32_t>(chunks, (uint32_t)c->num_cus * (uint32_t)blocks_per_cu));
+}
+
+void launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t* queue, uint32_t max_items) {
   int sa = stack_alloc_for(c);
   size_t lds = (size_t)sa * kBlock * sizeof(int);
-  uint32_t want = (max_items + kBlock - 1) / kBlock;
-  uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(want, (uint32_t)c->num_cus * 8));
+  uint32_t grid = chunk_grid(c, max_items, 6);
   unsigned long long* tot = c->d_totals.as<unsigned long long>();
   if (c->counters)
-    hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(kBlock), lds, c->stream, c->S, P, ctl, q_in, bins, cap, c->prm.stack_size, sa, tot);
+    hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(kBlock), lds, c->stream, c->S, P, ctl, queue, c->prm.stack_size, sa, grid, tot);
   else
-    hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(kBlock), lds, c->stream, c->S, P, ctl, q_in, bins, cap, c->prm.stack_size, sa, tot);
+    hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(kBlock), lds, c->stream, c->S, P, ctl, queue, c->prm.stack_size, sa, grid, tot);
 }
 
 int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames, int reset_first) {
@@ -410,7 +413,6 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   if (rcode) return rcode;
   Paths P = paths_of(c, rc.num_samples > 1);
   StepCtl* ctl = c->d_ctl.as<StepCtl>();
-  const uint32_t cap = (uint32_t)c->path_cap;
   const uint32_t total = rc.n_local * (uint32_t)n_frames;
   uint32_t* q[2] = {c->d_q0.as<uint32_t>(), c->d_q1.as<uint32_t>()};
   const uint32_t ew_grid = std::max<uint32_t>(1, std::min<uint32_t>((total + kBlock - 1) / kBlock, (uint32_t)c->num_cus * 16));
@@ -424,14 +426,15 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   for (int s = 0; s < n_steps; s++) {
     {
       ScopedSpan sp(c, T_INTERSECT);
-      launch_intersect(c, P, ctl + s, q[s & 1], c->d_bins.as<uint32_t>(), cap, total);
+      launch_intersect(c, P, ctl + s, q[s & 1], total);
     }
     {
       ScopedSpan sp(c, T_SHADE);
+      const uint32_t sgrid = chunk_grid(c, total, 8);
       if (p.importance_sampling)
-        hipLaunchKernelGGL(k_shade<true>, dim3(ew_grid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, c->d_bins.as<uint32_t>(), cap, q[(s + 1) & 1]);
+        hipLaunchKernelGGL(k_shade<true>, dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, q[s & 1], q[(s + 1) & 1], sgrid);
       else
-        hipLaunchKernelGGL(k_shade<false>, dim3(ew_grid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, c->d_bins.as<uint32_t>(), cap, q[(s + 1) & 1]);
+        hipLaunchKernelGGL(k_shade<false>, dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, q[s & 1], q[(s + 1) & 1], sgrid);
     }
     c->stats.intersect_launches++;
     c->stats.shade_launches++;
@@ -528,7 +531,7 @@ void ptmi_destroy(ptmi_ctx* c) {
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (DBuf* b : {&c->d_spheres, &c->d_sphere_info, &c->d_quads, &c->d_quad_mat, &c->d_tris, &c->d_pretri, &c->d_meshes, &c->d_xforms,
                   &c->d_mats, &c->d_nodes, &c->d_fb_own, &c->d_ray, &c->d_thr, &c->d_acc, &c->d_pixsum, &c->d_rng, &c->d_hit, &c->d_hitmat,
-                  &c->d_q0, &c->d_q1, &c->d_bins, &c->d_ctl, &c->d_totals, &c->d_scratch})
+                  &c->d_q0, &c->d_q1, &c->d_ctl, &c->d_totals, &c->d_scratch})
     b->release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -620,7 +623,7 @@ int ptmi_render(ptmi_ctx* c, const float* view16, uint32_t first_frame, uint32_t
   r = check_renderable(c);
   if (r) return r;
   size_t npix = (size_t)c->W * c->H;
-  uint32_t F = c->prm.frames_in_flight > 0 ? (uint32_t)c->prm.frames_in_flight : 8u;
+  uint32_t F = c->prm.frames_in_flight > 0 ? (uint32_t)c->prm.frames_in_flight : 16u;
   size_t max_f = std::max<size_t>(1, (size_t)0x0fffffff / npix);  // path ids stay below 2^28
   F = (uint32_t)std::min<size_t>(F, max_f);
   for (uint32_t done = 0; done < n_frames;) {
@@ -765,7 +768,7 @@ int ptmi_trace(ptmi_ctx* c, size_t n, const float* rays6, uint32_t* rng_inout, p
   HIP_TRY(c, hipMemcpyAsync(P.rng, rng.data(), n * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->d_q0.p, ident.data(), n * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(ctl, &ctl0, sizeof ctl0, hipMemcpyHostToDevice, c->stream));
-  launch_intersect(c, P, ctl, c->d_q0.as<uint32_t>(), c->d_bins.as<uint32_t>(), (uint32_t)c->path_cap, (uint32_t)n);
+  launch_intersect(c, P, ctl, c->d_q0.as<uint32_t>(), (uint32_t)n);
   HIP_TRY(c, c->d_scratch.ensure(n * sizeof(HitOut)));
   hipLaunchKernelGGL(k_resolve_hits, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->S, P, (uint32_t)n, c->d_scratch.as<HitOut>());
   HIP_TRY(c, hipGetLastError());

@@ -111,8 +111,9 @@ struct Paths {
 
 struct StepCtl {
   uint32_t n_rays;  // entries in this step's ray queue
-  uint32_t head;    // fetch cursor of the persistent intersect kernel
-  uint32_t bin_n[NUM_BINS];
+  uint32_t head_i;  // next chunk for k_intersect
+  uint32_t head_s;  // next chunk for k_shade
+  uint32_t pad;
 };
 
 struct RenderConst {

@@ -2,12 +2,12 @@
 //
 //   k_generate   one thread per (frame slot, owned pixel): seeds the RNG (main.wgsl:16), builds the
 //                camera ray (shootRay.wgsl), fills step 0's ray queue.
-//   k_intersect  persistent waves, one ray per lane, LDS traversal stacks: hitScene (hitRay.wgsl:1-113).
-//                Writes the closest-hit record and appends the path to the bin of its material class
-//                (one wave-aggregated atomic per bin).
-//   k_shade      walks the bins (wave-uniform material class): ray_color's loop body
+//   k_intersect  persistent blocks, one ray per lane, LDS traversal stacks: hitScene (hitRay.wgsl:1-113).
+//                Writes the closest-hit record and sorts each 2048-entry chunk of the ray queue by the
+//                material class of its hit, in place (LDS counting sort, ballot ranks).
+//   k_shade      consumes the sorted queue (bin-uniform waves): ray_color's loop body
 //                (traceRay.wgsl:10-80) + material_scatter + Russian roulette; survivors are compacted
-//                into the next step's ray queue, finished samples fold into the pixel colour.
+//                in LDS into the next step's ray queue, finished samples fold into the pixel colour.
 //   k_accumulate framebuffer read-modify-write of main.wgsl:22-27 for every frame slot, in frame order.
 #pragma once
 #include "ptmi_device.h"
@@ -37,57 +37,117 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderConst rc, Paths P, ui
   if (blockIdx.x == 0 && threadIdx.x == 0) ctl[0].n_rays = total;
 }
 
+// Work distribution (both k_intersect and k_shade): the step's ray queue is cut into chunks of kChunk
+// entries.  A block claims a chunk with ONE global atomic, its waves pull 64-entry sub-chunks from an
+// LDS counter, and all queue bookkeeping (sorting by material class, compaction of survivors) happens
+// in LDS.  Same-address global atomics cost ~11 ns each on MI355X, so per-wave global atomics would
+// cap a step at ~90 M rays/s per counter; per-chunk atomics are 32x rarer and off the critical path.
+constexpr int kChunk = 2048;
+// Small queues (the Russian-roulette tail of a batch) use smaller chunks so that the work still
+// spreads over ~target_blocks blocks instead of a few blocks walking 2048 rays each.
+DEV uint32_t chunk_size_for(uint32_t n, uint32_t target_blocks) {
+  uint32_t c = (n / target_blocks + 255u) & ~255u;
+  return min((uint32_t)kChunk, max(256u, c));
+}
+
+DEV int bin_of(const DevScene& S, uint32_t prim, int mat) {
+  if ((prim >> 28) == K_NONE) return BIN_MISS;
+  float ty = S.mats[4 * mat + 3].z;
+  return (ty == 0.0f) ? BIN_LAMBERTIAN : (ty == 1.0f) ? BIN_MIRROR : (ty == 2.0f) ? BIN_GLASS : (ty == 3.0f) ? BIN_ISOTROPIC : BIN_OTHER;
+}
+
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, Paths P, StepCtl* __restrict__ ctl, const uint32_t* __restrict__ q_in,
-                                                      uint32_t* __restrict__ q_bins, uint32_t cap, int stack_size, int stack_alloc,
-                                                      unsigned long long* __restrict__ totals) {
+__global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ queue, int stack_size,
+                                                      int stack_alloc, uint32_t target_blocks, unsigned long long* __restrict__ totals) {
   extern __shared__ int lds_stack[];
+  __shared__ uint32_t s_pid[kChunk];
+  __shared__ uint16_t s_key[kChunk];  // bin | rank-within-bin << 3
+  __shared__ uint32_t s_cnt[NUM_BINS + 2];
+  __shared__ uint32_t s_chunk, s_next;
   const int lane = lane_id();
   int* stk = lds_stack + (threadIdx.x >> 6) * (stack_alloc * 64) + lane;
   const uint32_t n = ctl->n_rays;
+  const uint32_t csz = chunk_size_for(n, target_blocks);
   Counters cn = {0, 0, 0, 0, 0};
 
   while (true) {
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&ctl->head, 64u);
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (threadIdx.x == 0) {
+      s_chunk = atomicAdd(&ctl->head_i, 1u);
+      s_next = 0;
+    }
+    if (threadIdx.x < NUM_BINS) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = s_chunk * csz;
     if (base >= n) break;
-    uint32_t i = base + lane;
-    bool active = i < n;
-    int bin = -1;
-    uint32_t pid = 0;
-    if (active) {
-      pid = q_in[i];
-      float4 r0 = P.ray[2 * (size_t)pid], r1 = P.ray[2 * (size_t)pid + 1];
-      f3 o = mk3(r0), d = mk3(r1);
-      Closest c;
-      c.t = kMaxFloat;
-      c.u = c.v = 0.0f;
-      c.prim = K_NONE;
-      c.mat = 0;
-      if (S.n_spheres > 0) {
-        uint32_t rng = P.rng[pid];
-        uint32_t rng0 = rng;
-        hit_spheres<COUNT>(S, o, d, rng, c, cn);
-        if (rng != rng0) P.rng[pid] = rng;
+    const uint32_t m = min(csz, n - base);
+
+    while (true) {
+      uint32_t sub = 0;
+      if (lane == 0) sub = atomicAdd(&s_next, 64u);
+      sub = (uint32_t)__builtin_amdgcn_readfirstlane((int)sub);
+      if (sub >= m) break;
+      const uint32_t j = sub + lane;
+      const bool active = j < m;
+      int bin = -1;
+      uint32_t pid = 0;
+      if (active) {
+        pid = queue[base + j];
+        float4 r0 = P.ray[2 * (size_t)pid], r1 = P.ray[2 * (size_t)pid + 1];
+        f3 o = mk3(r0), d = mk3(r1);
+        Closest c;
+        c.t = kMaxFloat;
+        c.u = c.v = 0.0f;
+        c.prim = K_NONE;
+        c.mat = 0;
+        if (S.n_spheres > 0) {
+          uint32_t rng = P.rng[pid];
+          uint32_t rng0 = rng;
+          hit_spheres<COUNT>(S, o, d, rng, c, cn);
+          if (rng != rng0) P.rng[pid] = rng;
+        }
+        hit_quads<COUNT>(S, o, d, c, cn);
+        traverse_bvh<COUNT>(S, o, d, stack_size, stk, c, cn);
+        P.hit[pid] = make_float4(c.t, c.u, c.v, __uint_as_float(c.prim));
+        if ((c.prim >> 28) != K_NONE) P.hitmat[pid] = (uint32_t)c.mat;
+        bin = bin_of(S, c.prim, c.mat);
       }
-      hit_quads<COUNT>(S, o, d, c, cn);
-      traverse_bvh<COUNT>(S, o, d, stack_size, stk, c, cn);
-      P.hit[pid] = make_float4(c.t, c.u, c.v, __uint_as_float(c.prim));
-      if ((c.prim >> 28) == K_NONE) {
-        bin = BIN_MISS;
-      } else {
-        P.hitmat[pid] = (uint32_t)c.mat;
-        float ty = S.mats[4 * c.mat + 3].z;
-        bin = (ty == 0.0f) ? BIN_LAMBERTIAN : (ty == 1.0f) ? BIN_MIRROR : (ty == 2.0f) ? BIN_GLASS : (ty == 3.0f) ? BIN_ISOTROPIC : BIN_OTHER;
+      // rank of every entry within its bin for this chunk (counting sort, pass 1)
+      uint32_t rank = 0;
+#pragma unroll
+      for (int b = 0; b < NUM_BINS; b++) {
+        const bool mine = (bin == b);
+        const uint64_t mk = __ballot(mine);
+        if (mk) {
+          const int leader = __ffsll((unsigned long long)mk) - 1;
+          uint32_t bb = 0;
+          if (lane == leader) bb = atomicAdd(&s_cnt[b], (uint32_t)__popcll(mk));
+          bb = (uint32_t)__shfl((int)bb, leader, 64);
+          if (mine) rank = bb + lanes_below(mk);
+        }
+      }
+      if (active) {
+        s_pid[j] = pid;
+        s_key[j] = (uint16_t)((uint32_t)bin | (rank << 3));
       }
     }
+    __syncthreads();
+    // pass 2: scatter the chunk back IN PLACE, grouped by bin -> the shade kernel sees bin-uniform waves
+    uint32_t off[NUM_BINS];
+    uint32_t run = 0;
 #pragma unroll
     for (int b = 0; b < NUM_BINS; b++) {
-      bool mine = (bin == b);
-      uint32_t slot = wave_append(&ctl->bin_n[b], mine);
-      if (mine) q_bins[(size_t)b * cap + slot] = pid;
+      off[b] = run;
+      run += s_cnt[b];
     }
+    for (uint32_t j = threadIdx.x; j < m; j += kBlock) {
+      const uint32_t key = s_key[j];
+      const uint32_t b = key & 7u;
+      uint32_t o = off[0];
+#pragma unroll
+      for (int k = 1; k < NUM_BINS; k++) o = (b == (uint32_t)k) ? off[k] : o;
+      queue[base + o + (key >> 3)] = s_pid[j];
+    }
+    __syncthreads();
   }
 
   if (COUNT) {
@@ -96,7 +156,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, Paths P, StepC
 #pragma unroll
     for (int k = 0; k < 5; k++) {
       unsigned long long x = v[k];
-      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+      for (int off2 = 32; off2 > 0; off2 >>= 1) x += __shfl_down(x, off2, 64);
       if (lane == 0 && x) atomicAdd(&totals[2 + k], x);
     }
   }
@@ -105,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, Paths P, StepC
 // One path's iteration of the `for i < MAX_BOUNCES` loop body after hitScene (traceRay.wgsl:10-80).
 // Returns true when the path continues with a new ray (already stored), false when this slot is done.
 template <bool IS>
-DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, int bin, uint32_t pid, const QuadL& L) {
+DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, uint32_t pid, const QuadL& L) {
   float4 r0 = P.ray[2 * (size_t)pid], r1 = P.ray[2 * (size_t)pid + 1];
   f3 o = mk3(r0), d = mk3(r1);
   float4 T4 = P.thr[pid], A4 = P.acc[pid];
@@ -116,14 +176,16 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, int
   bool sample_done = false;
   f3 radiance = acc;
   f3 no = o, nd = d;
+  const float4 h = P.hit[pid];
 
-  if (bin == BIN_MISS) {  // traceRay.wgsl:12-16
+  if ((__float_as_uint(h.w) >> 28) == K_NONE) {  // traceRay.wgsl:12-16
     radiance = acc + (mk3(rc.bg[0], rc.bg[1], rc.bg[2]) * T);
     sample_done = true;
   } else {
-    float4 h = P.hit[pid];
     int mat = (int)P.hitmat[pid];
     Material m = load_material(S, mat);
+    // the queue is sorted by this class within each chunk, so `bin` is wave-uniform almost everywhere
+    const int bin = (m.type == 0.0f) ? BIN_LAMBERTIAN : (m.type == 1.0f) ? BIN_MIRROR : (m.type == 2.0f) ? BIN_GLASS : (m.type == 3.0f) ? BIN_ISOTROPIC : BIN_OTHER;
     HitGeom g = resolve_hit(S, o, d, h.x, h.y, h.z, __float_as_uint(h.w));
     f3 emission = m.emission;
     if (!g.front) emission = mk3(0, 0, 0);  // traceRay.wgsl:19-22
@@ -225,28 +287,52 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, int
 }
 
 template <bool IS>
-__global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl,
-                                                  const uint32_t* __restrict__ q_bins, uint32_t cap, uint32_t* __restrict__ q_next) {
+__global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, const uint32_t* __restrict__ queue,
+                                                  uint32_t* __restrict__ q_next, uint32_t target_blocks) {
+  __shared__ uint32_t s_out[kChunk];
+  __shared__ uint32_t s_chunk, s_next, s_nout, s_base;
   const QuadL L = load_light(S);
-  const uint32_t wave_stride = gridDim.x * kBlock;
-  const uint32_t wave_base = (blockIdx.x * kBlock + threadIdx.x) & ~63u;
   const int lane = lane_id();
-#pragma unroll 1
-  for (int b = 0; b < NUM_BINS; b++) {
-    const uint32_t n = ctl->bin_n[b];
-    const uint32_t* q = q_bins + (size_t)b * cap;
-    for (uint32_t base = wave_base; base < n; base += wave_stride) {
-      uint32_t i = base + lane;
-      bool active = i < n;
+  const uint32_t n = ctl->n_rays;
+  const uint32_t csz = chunk_size_for(n, target_blocks);
+  while (true) {
+    if (threadIdx.x == 0) {
+      s_chunk = atomicAdd(&ctl->head_s, 1u);
+      s_next = 0;
+      s_nout = 0;
+    }
+    __syncthreads();
+    const uint32_t base = s_chunk * csz;
+    if (base >= n) break;
+    const uint32_t m = min(csz, n - base);
+    while (true) {
+      uint32_t sub = 0;
+      if (lane == 0) sub = atomicAdd(&s_next, 64u);
+      sub = (uint32_t)__builtin_amdgcn_readfirstlane((int)sub);
+      if (sub >= m) break;
+      const uint32_t j = sub + lane;
       bool survive = false;
       uint32_t pid = 0;
-      if (active) {
-        pid = q[i];
-        survive = shade_one<IS>(S, rc, P, b, pid, L);
+      if (j < m) {
+        pid = queue[base + j];
+        survive = shade_one<IS>(S, rc, P, pid, L);
       }
-      uint32_t slot = wave_append(&ctl[1].n_rays, survive);
-      if (survive) q_next[slot] = pid;
+      const uint64_t mk = __ballot(survive);
+      if (mk) {
+        const int leader = __ffsll((unsigned long long)mk) - 1;
+        uint32_t bb = 0;
+        if (lane == leader) bb = atomicAdd(&s_nout, (uint32_t)__popcll(mk));
+        bb = (uint32_t)__shfl((int)bb, leader, 64);
+        if (survive) s_out[bb + lanes_below(mk)] = pid;
+      }
     }
+    __syncthreads();
+    const uint32_t nout = s_nout;
+    if (threadIdx.x == 0 && nout) s_base = atomicAdd(&ctl[1].n_rays, nout);
+    __syncthreads();
+    const uint32_t ob = s_base;
+    for (uint32_t j = threadIdx.x; j < nout; j += kBlock) q_next[ob + j] = s_out[j];
+    __syncthreads();
   }
 }
 
