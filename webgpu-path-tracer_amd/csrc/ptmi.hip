@@ -58,7 +58,7 @@ struct ptmi_ctx {
   std::vector<int32_t> h_meshes;
   bool scene_dirty = true;
 
-  DBuf d_spheres, d_sphere_info, d_quads, d_quad_mat, d_tris, d_pretri, d_meshes, d_xforms, d_mats, d_nodes;
+  DBuf d_spheres, d_sphere_info, d_quads, d_quad_mat, d_tris, d_pretri, d_meshes, d_xforms, d_mats, d_pairs, d_leaf_table;
   DevScene S{};
   int bvh_depth = 0;             // max number of inner nodes on a root-to-leaf path
   bool has_unknown_material = false;
@@ -224,15 +224,18 @@ int prepare_scene(ptmi_ctx* c) {
     o[14] = ABx * ACy - ABy * ACx;
     o[15] = 0.0f;
   }
-  // node32 digest + tree check.  Children always have larger indices than their parent (left = i+1,
+  // Tree check + pair64 digest.  Children always have larger indices than their parent (left = i+1,
   // right > i+1), so a walk from the root terminates; "every node reached at most once" excludes
   // shared subtrees (which could make a traversal exponentially long).
-  std::vector<float> node32(8 * (size_t)n_node);
+  std::vector<float> pairs;
+  std::vector<int32_t> leaf_table;
+  float root_lo[4] = {0, 0, 0, 0}, root_hi[4] = {0, 0, 0, 0};
   c->bvh_depth = 0;
   if (n_node > 0) {
-    std::vector<uint8_t> seen((size_t)n_node, 0);
-    std::vector<std::pair<int, int>> st;  // node, inner depth so far
+    std::vector<uint8_t> seen((size_t)n_node, 0);  // 1 = inner, 2 = leaf
+    std::vector<std::pair<int, int>> st;           // node, inner depth so far
     st.emplace_back(0, 0);
+    size_t n_inner = 0;
     while (!st.empty()) {
       auto [i, depth] = st.back();
       st.pop_back();
@@ -240,20 +243,14 @@ int prepare_scene(ptmi_ctx* c) {
         snprintf(msg, sizeof msg, "bvh: node %d reachable twice (not a tree)", i);
         return fail(c, PTMI_ERR_BAD_SCENE, msg);
       }
-      seen[i] = 1;
       const float* nd = &c->h_bvh[12 * (size_t)i];
-      float* o = &node32[8 * (size_t)i];
-      o[0] = nd[0], o[1] = nd[1], o[2] = nd[2];
-      o[4] = nd[4], o[5] = nd[5], o[6] = nd[6];
-      int32_t a, b;
       if ((int)nd[7] == 2) {  // leaf (hitRay.wgsl:45,56)
         int first, cnt = (int)nd[9];
         if (!(nd[9] >= 0.0f) || cnt < 0 || (cnt > 0 && (!id_from_float(nd[8], n_tri, &first) || first + cnt > n_tri))) {
           snprintf(msg, sizeof msg, "bvh: leaf %d references triangles outside [0,%d)", i, n_tri);
           return fail(c, PTMI_ERR_BAD_SCENE, msg);
         }
-        a = cnt > 0 ? (int)nd[8] : 0;
-        b = (int32_t)((uint32_t)cnt | 0x80000000u);
+        seen[i] = 2;
         c->bvh_depth = std::max(c->bvh_depth, depth);
       } else {
         int right, axis = (int)nd[11];
@@ -261,14 +258,48 @@ int prepare_scene(ptmi_ctx* c) {
           snprintf(msg, sizeof msg, "bvh: inner node %d has right_offset/axis out of range", i);
           return fail(c, PTMI_ERR_BAD_SCENE, msg);
         }
-        a = right;
-        b = axis;
+        seen[i] = 1;
+        n_inner++;
         st.emplace_back(right, depth + 1);
         st.emplace_back(i + 1, depth + 1);
       }
-      memcpy(&o[3], &a, 4);
-      memcpy(&o[7], &b, 4);
     }
+    std::vector<int32_t> rank((size_t)n_node, -1);
+    int32_t r = 0;
+    for (int i = 0; i < n_node; i++)
+      if (seen[i] == 1) rank[i] = r++;
+    auto ref_of = [&](int j) -> uint32_t {
+      const float* nd = &c->h_bvh[12 * (size_t)j];
+      if (seen[j] == 1) return (uint32_t)rank[j];
+      int cnt = (int)nd[9];
+      if (cnt == 1) return REF_LEAF | (uint32_t)(int)nd[8];
+      leaf_table.push_back(cnt > 0 ? (int)nd[8] : 0);
+      leaf_table.push_back(cnt);
+      return REF_LEAF | REF_MULTI | (uint32_t)(leaf_table.size() / 2 - 1);
+    };
+    pairs.assign(16 * n_inner, 0.0f);
+    for (int i = 0; i < n_node; i++) {
+      if (seen[i] != 1) continue;
+      const float* nd = &c->h_bvh[12 * (size_t)i];
+      const int L = i + 1, R = (int)nd[3];
+      const float *nl = &c->h_bvh[12 * (size_t)L], *nr = &c->h_bvh[12 * (size_t)R];
+      float* o = &pairs[16 * (size_t)rank[i]];
+      uint32_t rl = ref_of(L), rr = ref_of(R);
+      int32_t axis = (int)nd[11];
+      o[0] = nl[0], o[1] = nl[1], o[2] = nl[2];
+      memcpy(&o[3], &rl, 4);
+      o[4] = nl[4], o[5] = nl[5], o[6] = nl[6];
+      memcpy(&o[7], &rr, 4);
+      o[8] = nr[0], o[9] = nr[1], o[10] = nr[2];
+      memcpy(&o[11], &axis, 4);
+      o[12] = nr[4], o[13] = nr[5], o[14] = nr[6];
+      o[15] = 0.0f;
+    }
+    const float* rn = &c->h_bvh[0];
+    uint32_t rref = ref_of(0);
+    root_lo[0] = rn[0], root_lo[1] = rn[1], root_lo[2] = rn[2];
+    memcpy(&root_lo[3], &rref, 4);
+    root_hi[0] = rn[4], root_hi[1] = rn[5], root_hi[2] = rn[6];
   }
 
   auto up = [&](DBuf& d, const void* src, size_t bytes) -> hipError_t {
@@ -286,7 +317,8 @@ int prepare_scene(ptmi_ctx* c) {
   HIP_TRY(c, up(c->d_meshes, c->h_meshes.data(), c->h_meshes.size() * 4));
   HIP_TRY(c, up(c->d_xforms, c->h_xforms.data(), c->h_xforms.size() * 4));
   HIP_TRY(c, up(c->d_mats, c->h_mats.data(), c->h_mats.size() * 4));
-  HIP_TRY(c, up(c->d_nodes, node32.data(), node32.size() * 4));
+  HIP_TRY(c, up(c->d_pairs, pairs.data(), pairs.size() * 4));
+  HIP_TRY(c, up(c->d_leaf_table, leaf_table.data(), leaf_table.size() * 4));
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // the staging vectors die at scope exit
 
   DevScene& S = c->S;
@@ -299,7 +331,10 @@ int prepare_scene(ptmi_ctx* c) {
   S.meshes = c->d_meshes.as<int4>();
   S.xforms = c->d_xforms.as<float4>();
   S.mats = c->d_mats.as<float4>();
-  S.nodes = c->d_nodes.as<float4>();
+  S.pairs = c->d_pairs.as<float4>();
+  S.leaf_table = c->d_leaf_table.as<int2>();
+  S.root_lo = make_float4(root_lo[0], root_lo[1], root_lo[2], root_lo[3]);
+  S.root_hi = make_float4(root_hi[0], root_hi[1], root_hi[2], root_hi[3]);
   S.n_spheres = n_sph, S.n_quads = n_quad, S.n_tris = n_tri, S.n_meshes = n_mesh, S.n_xforms = n_xf, S.n_mats = n_mat, S.n_nodes = n_node;
   S.light_quad = light;
   c->scene_dirty = false;
@@ -365,7 +400,7 @@ uint32_t chunk_grid(const ptmi_ctx* c, uint32_t max_items, int blocks_per_cu) {
 
 void launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t* queue, uint32_t max_items) {
   int sa = stack_alloc_for(c);
-  size_t lds = (size_t)sa * kBlock * sizeof(int);
+  size_t lds = (size_t)sa * 2 * kBlock * sizeof(int);  // two words per stack entry
   uint32_t grid = chunk_grid(c, max_items, 6);
   unsigned long long* tot = c->d_totals.as<unsigned long long>();
   if (c->counters)
@@ -530,7 +565,7 @@ void ptmi_destroy(ptmi_ctx* c) {
   drain_spans(c);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (DBuf* b : {&c->d_spheres, &c->d_sphere_info, &c->d_quads, &c->d_quad_mat, &c->d_tris, &c->d_pretri, &c->d_meshes, &c->d_xforms,
-                  &c->d_mats, &c->d_nodes, &c->d_fb_own, &c->d_ray, &c->d_thr, &c->d_acc, &c->d_pixsum, &c->d_rng, &c->d_hit, &c->d_hitmat,
+                  &c->d_mats, &c->d_pairs, &c->d_leaf_table, &c->d_fb_own, &c->d_ray, &c->d_thr, &c->d_acc, &c->d_pixsum, &c->d_rng, &c->d_hit, &c->d_hitmat,
                   &c->d_q0, &c->d_q1, &c->d_ctl, &c->d_totals, &c->d_scratch})
     b->release();
   if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -79,10 +79,15 @@ DEV float rand2D(uint32_t& s) {
 
 // ---- scene as the kernels see it -------------------------------------------------------------------
 // Raw arrays keep the reference's byte layout.  Two digests are derived at upload:
-//   node32 : {min.xyz, a} {max.xyz, b}   leaf: a = prim_id, b = prim_count | 0x80000000
-//                                          inner: a = right_offset, b = axis           (32 B, aligned)
+//   pair64 : one 64-byte record per INNER node holding BOTH children's boxes, so that one fetch decides
+//            two box tests:  {L.min.xyz, L.ref} {L.max.xyz, R.ref} {R.min.xyz, axis} {R.max.xyz, 0}
+//            with L = node i+1, R = node right_offset(i).  A child ref is
+//              inner : index of the child's own pair record
+//              leaf  : REF_LEAF | prim_id                      (prim_count == 1, the reference's builder)
+//                      REF_LEAF | REF_MULTI | leaf_table index (any other prim_count: {prim_id, count})
 //   pretri : {A.xyz, mesh_id} {AB.xyz,0} {AC.xyz,0} {cross(AB,AC).xyz,0}                (64 B, aligned)
-// Both hold values the shader would compute itself (common.wgsl:199-201) — same f32 operations.
+// Both hold values the shader would load or compute itself (common.wgsl:199-201) — same f32 operations.
+constexpr uint32_t REF_LEAF = 0x80000000u, REF_MULTI = 0x40000000u, REF_B = 0x20000000u, REF_A = 0x10000000u, REF_IDX = 0x0fffffffu;
 struct DevScene {
   const float4* spheres;  // 2 float4 / sphere
   const int2* sphere_info;  // {material_id, is_volume}
@@ -93,7 +98,9 @@ struct DevScene {
   const int4* meshes;
   const float4* xforms;  // 8 float4 / object: model[4], invModel[4]
   const float4* mats;    // 4 float4 / material
-  const float4* nodes;   // 2 float4 / node
+  const float4* pairs;   // 4 float4 / inner node
+  const int2* leaf_table;
+  float4 root_lo, root_hi;  // root box; root_lo.w = root's child ref
   int n_spheres, n_quads, n_tris, n_meshes, n_xforms, n_mats, n_nodes;
   int light_quad;  // first quad with emission.x > 0 (common.wgsl:258-269), -1 if none
 };
@@ -319,45 +326,92 @@ DEV void hit_triangle(const DevScene& S, int k, f3 o, f3 d, ObjRay& orr, Closest
   if (COUNT) cn.mat_fetches++;
 }
 
-// shaders/hitRay.wgsl:42-110 — stack traversal, front-to-back by the split axis.  `stk` is this lane's
-// column of the LDS stack: entry d lives at stk[d * 64] (lane-major rows -> conflict-free ds_write/read).
+// t-interval of a ray against one box, the closest-independent part of hit_aabb (common.wgsl:246-253):
+// ts = max(tmin, max3(tsmaller)), tb = min3(tbigger); the box passes iff min(closest, tb) > ts.
+DEV void slab(float4 lo, float4 hi, f3 o, f3 inv, float& ts, float& tb) {
+  float t0x = (lo.x - o.x) * inv.x, t0y = (lo.y - o.y) * inv.y, t0z = (lo.z - o.z) * inv.z;
+  float t1x = (hi.x - o.x) * inv.x, t1y = (hi.y - o.y) * inv.y, t1z = (hi.z - o.z) * inv.z;
+  float sx = ptm_min(t0x, t1x), sy = ptm_min(t0y, t1y), sz = ptm_min(t0z, t1z);
+  float bx = ptm_max(t0x, t1x), by = ptm_max(t0y, t1y), bz = ptm_max(t0z, t1z);
+  ts = ptm_max(kTmin, ptm_max(sx, ptm_max(sy, sz)));
+  tb = ptm_min(bx, ptm_min(by, bz));
+}
+
+template <bool COUNT>
+DEV void visit_leaf(const DevScene& S, uint32_t ref, f3 o, f3 d, ObjRay& orr, Closest& c, Counters& cn) {
+  if (ref & REF_MULTI) {  // hitRay.wgsl:59-68 with prim_count != 1 (external BVHs)
+    int2 lc = S.leaf_table[ref & REF_IDX];
+    for (int j = 0; j < lc.y; j++) hit_triangle<COUNT>(S, lc.x + j, o, d, orr, c, cn);
+  } else {
+    hit_triangle<COUNT>(S, (int)(ref & REF_IDX), o, d, orr, c, cn);
+  }
+}
+
+// shaders/hitRay.wgsl:42-110 — stack traversal, front-to-back by the split axis, with the reference's
+// exact visit order, box-test outcomes and stack depth (Q7).  What differs is only WHERE the bytes come
+// from: an inner node's record carries both children's boxes, the near child is tested at once (the
+// reference tests it in its very next iteration with the same closest_so_far), and the far child is
+// pushed together with its closest-independent interval start `ts` and two flag bits, so that when the
+// reference would pop and re-test it against the then-current closest_so_far, the outcome
+//     min(closest, tb) > ts   ==   isnan(closest) ? B : (A && closest > ts)
+// (A = tb > ts || isnan(tb), B = tb > ts; min drops NaNs, ptmi_math.h) is evaluated from the stack
+// entry alone.  `stk` is this lane's column of the LDS stack: word w of entry e lives at stk[(2e+w)*64].
 template <bool COUNT>
 DEV void traverse_bvh(const DevScene& S, f3 o, f3 d, int stack_size, int* __restrict__ stk, Closest& c, Counters& cn) {
   if (S.n_nodes <= 0) return;  // no triangle geometry (an empty binding cannot exist in WebGPU)
-  f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   ObjRay orr;
   orr.mesh = -1;
   orr.o = orr.d = mk3(0, 0, 0);
-  int sp = 0, cur = 0;
+  if (COUNT) cn.node_visits++;
+  if (!hit_aabb(S.root_lo, S.root_hi, c.t, o, inv)) return;
+  const uint32_t root = __float_as_uint(S.root_lo.w);
+  if (root & REF_LEAF) {
+    visit_leaf<COUNT>(S, root, o, d, orr, c, cn);
+    return;
+  }
+  int sp = 0;
+  uint32_t cur = root & REF_IDX;
   while (true) {
-    float4 lo = S.nodes[2 * (size_t)cur], hi = S.nodes[2 * (size_t)cur + 1];
-    int a = __float_as_int(lo.w), b = __float_as_int(hi.w);
+    const float4* pr = S.pairs + 4 * (size_t)cur;
+    const float4 f0 = pr[0], f1 = pr[1], f2 = pr[2], f3v = pr[3];
+    float tsL, tbL, tsR, tbR;
+    slab(f0, f1, o, inv, tsL, tbL);
+    slab(f2, f3v, o, inv, tsR, tbR);
+    const int axis = __float_as_int(f2.w);
+    const float dax = (axis == 0) ? d.x : ((axis == 1) ? d.y : d.z);
+    const bool neg = dax < 0;  // hitRay.wgsl:80: push the left child, go right
+    const uint32_t refL = __float_as_uint(f0.w), refR = __float_as_uint(f1.w);
+    const uint32_t nearRef = neg ? refR : refL;
+    uint32_t farRef = neg ? refL : refR;
+    const float tsN = neg ? tsR : tsL, tbN = neg ? tbR : tbL;
+    const float tsF = neg ? tsL : tsR, tbF = neg ? tbL : tbR;
+    const bool fB = tbF > tsF;
+    const bool fA = fB || (tbF != tbF);
+    farRef |= (fA ? REF_A : 0u) | (fB ? REF_B : 0u);
+    stk[(2 * sp) * 64] = (int)farRef;
+    stk[(2 * sp + 1) * 64] = __float_as_int(tsF);
+    sp++;
+    if (sp >= stack_size) return;  // hitRay.wgsl:106-109 (Q7)
     if (COUNT) cn.node_visits++;
-    if (hit_aabb(lo, hi, c.t, o, inv)) {
-      if (b < 0) {  // leaf
-        int cnt = b & 0x7fffffff;
-        for (int j = 0; j < cnt; j++) hit_triangle<COUNT>(S, a + j, o, d, orr, c, cn);
-        if (sp == 0) break;
-        sp--;
-        cur = stk[sp * 64];
-      } else {
-        float dax = (b == 0) ? d.x : ((b == 1) ? d.y : d.z);
-        if (dax < 0) {
-          stk[sp * 64] = cur + 1;
-          sp++;
-          cur = a;
-        } else {
-          stk[sp * 64] = a;
-          sp++;
-          cur = cur + 1;
-        }
-      }
-    } else {
-      if (sp == 0) break;
-      sp--;
-      cur = stk[sp * 64];
+    uint32_t next = 0xffffffffu;
+    if (ptm_min(c.t, tbN) > tsN) {
+      if (nearRef & REF_LEAF) visit_leaf<COUNT>(S, nearRef, o, d, orr, c, cn);
+      else next = nearRef;
     }
-    if (sp >= stack_size) break;  // hitRay.wgsl:106-109 (Q7)
+    while (next == 0xffffffffu) {
+      if (sp == 0) return;
+      sp--;
+      const uint32_t e = (uint32_t)stk[(2 * sp) * 64];
+      const float ts = __int_as_float(stk[(2 * sp + 1) * 64]);
+      if (COUNT) cn.node_visits++;
+      const bool pass = (c.t != c.t) ? ((e & REF_B) != 0u) : (((e & REF_A) != 0u) && (c.t > ts));
+      if (pass) {
+        if (e & REF_LEAF) visit_leaf<COUNT>(S, e, o, d, orr, c, cn);
+        else next = e & REF_IDX;
+      }
+    }
+    cur = next;
   }
 }
 

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, Paths P, StepC
   __shared__ uint32_t s_cnt[NUM_BINS + 2];
   __shared__ uint32_t s_chunk, s_next;
   const int lane = lane_id();
-  int* stk = lds_stack + (threadIdx.x >> 6) * (stack_alloc * 64) + lane;
+  int* stk = lds_stack + (threadIdx.x >> 6) * (stack_alloc * 2 * 64) + lane;
   const uint32_t n = ctl->n_rays;
   const uint32_t csz = chunk_size_for(n, target_blocks);
   Counters cn = {0, 0, 0, 0, 0};
