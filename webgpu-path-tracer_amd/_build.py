@@ -54,7 +54,7 @@ def build_addon(force=False):
         return None
     if not force and _newer(ADDON, [src, os.path.join(ROOT, "include", "ptmi.h")]):
         return ADDON
-    _run(["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-Wall", "-I", inc, "-I", os.path.join(ROOT, "include"), "-o", ADDON, src, "-ldl"])
+    _run(["gcc", "-O2", "-fPIC", "-shared", "-std=gnu11", "-Wall", "-DNODE_GYP_MODULE_NAME=ptmi", "-I", inc, "-I", os.path.join(ROOT, "include"), "-o", ADDON, src, "-ldl"])
     return ADDON
 
 

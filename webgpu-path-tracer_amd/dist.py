@@ -8,8 +8,9 @@ adds x + 0 + ... + 0, so the N-GPU image is bit-identical to the 1-GPU image.
 """
 import os
 
-TILE_PIXELS = 64 * 1024  # contiguous pixel runs per shard tile: long enough for coherent primary rays,
-                         # short enough (32 tiles at 1080p) to balance background vs. geometry rows
+TILE_PIXELS = 4096  # contiguous pixel runs per shard tile (about two 1080p rows): long enough for coherent
+                    # primary-ray waves, short enough (506 tiles at 1080p) that every rank samples every
+                    # image region and the per-rank work is balanced
 
 
 def env_rank_world():
