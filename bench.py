@@ -35,10 +35,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=["c2"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3"], help="c2 = BASELINE configs[1] (default, the metric's config); c3 = configs[2], dragon-class 871k triangles")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=64, help="progressive frames per step and per GPU")
+    ap.add_argument("--spp", type=int, default=0, help="progressive frames per step and per GPU (0 = the config's: 64 for c2, 256 for c3)")
+    ap.add_argument("--stack-size", type=int, default=0)
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--frames-in-flight", type=int, default=0)
     ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the cpu_baseline (the 1-GPU box's CPU share)")
@@ -56,12 +57,19 @@ def main():
     torch.cuda.set_device(local)
 
     W, H = args.width, args.height
+    if args.spp <= 0:
+        args.spp = 64 if args.workload == "c2" else 256
     spp = args.spp * world
-    buffers = pkg.scenes.golden_buffers("c2")  # reference-generated buffers of configs[1] (tests/golden)
+    if args.workload == "c2":
+        buffers = pkg.scenes.golden_buffers("c2")  # reference-generated buffers of configs[1] (tests/golden)
+        label, stack = "configs[1]: Cornell + monkey_968.obj (967 tris)", args.stack_size or 20
+    else:
+        buffers = pkg.scenes.c3_scene().buffers(native=pkg.ptmi.NativeHost())  # procedural stand-in, 871,414 tris
+        label, stack = "configs[2]: Cornell + dragon-class mesh (871,414 tris, procedural stand-in for stanfordDragon.obj)", args.stack_size or 24
     view = pkg.scenes.camera_view(*pkg.scenes.CAMERAS["cornell"])
     ctx = pkg.Context(local)
     ctx.upload_scene(buffers)
-    ctx.set_params(max_bounces=args.bounces, frames_in_flight=args.frames_in_flight)
+    ctx.set_params(max_bounces=args.bounces, frames_in_flight=args.frames_in_flight, stack_size=stack)
     ctx.resize(W, H)
     fb_t = None
     if world > 1:
@@ -133,7 +141,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "configs[1]: Cornell + monkey_968.obj (967 tris), %dx%d, %d spp per GPU (%d total), %d bounces" % (W, H, args.spp, spp, args.bounces),
+                "workload": "%s, %dx%d, %d spp per GPU (%d total), %d bounces, stack_size %d" % (label, W, H, args.spp, spp, args.bounces, stack),
                 "rays_per_step": rays_all / args.steps,
                 "mpaths_per_s": paths_all / dt_max / 1e6,
                 "parallelism": "pixel tiles x%d + 1 RCCL reduce" % world if world > 1 else "1 GPU",
@@ -157,11 +165,11 @@ def main():
 
             cores = min(ptm_oracle.max_threads(), args.cpu_threads)
             t = time.perf_counter()
-            _, ost = ptm_oracle.render(buffers, W, H, view, 1, 1, max_bounces=args.bounces, threads=cores)
+            _, ost = ptm_oracle.render(buffers, W, H, view, 1, 1, max_bounces=args.bounces, stack_size=stack, threads=cores)
             one = time.perf_counter() - t
             frames = int(max(1, min(args.spp, args.cpu_seconds / max(one, 1e-3))))
             t = time.perf_counter()
-            _, ost = ptm_oracle.render(buffers, W, H, view, 1, frames, max_bounces=args.bounces, threads=cores)
+            _, ost = ptm_oracle.render(buffers, W, H, view, 1, frames, max_bounces=args.bounces, stack_size=stack, threads=cores)
             cdt = time.perf_counter() - t
             out["cpu_baseline"] = {
                 "value": ost["rays"] / cdt / 1e6,

@@ -107,3 +107,18 @@ def test_gl_matrix_known_answers(pkg):
     cam = mat4.create()
     mat4.targetTo(cam, [0, 0, 5], [0, 0, 0], [0, 1, 0])
     assert np.allclose(cam, [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 5, 1])
+
+
+def test_dragon_class_generator_is_exact_and_deterministic(pkg):
+    import hashlib
+
+    for n in (871414 // 64, 1001):
+        m = pkg.scenes.dragon_class_mesh(n, seed=1)
+        assert m["vertices"].size == 9 * n and m["normals"].size == 9 * n
+        nn = np.linalg.norm(m["normals"].reshape(-1, 3), axis=1)
+        assert np.abs(nn - 1).max() < 1e-6
+        v = m["vertices"].reshape(-1, 3)
+        assert abs((v.max(0) - v.min(0)).max() - 1.0) < 1e-6
+        again = pkg.scenes.dragon_class_mesh(n, seed=1)
+        assert hashlib.sha256(m["vertices"].tobytes()).digest() == hashlib.sha256(again["vertices"].tobytes()).digest()
+    assert not np.array_equal(pkg.scenes.dragon_class_mesh(1001, 1)["vertices"], pkg.scenes.dragon_class_mesh(1001, 2)["vertices"])

@@ -214,3 +214,24 @@ def test_resolve_rgba8(ctx, pkg):
     ref = np.clip((v1 * (2.51 * v1 + 0.03)) / (v1 * (2.43 * v1 + 0.59) + 0.14), 0, 1) ** (1 / 2.2)
     assert img.shape == (64, 64, 4) and (img[..., 3] == 255).all()
     assert np.abs(img[..., :3].astype(np.float64) - ref * 255).max() <= 1.0
+
+
+def test_dragon_class_scene_bit_exact(ctx, pkg, oracle):
+    """BASELINE configs[2] geometry (871,414 triangles, BVH depth 20, stack_size 24) at reduced resolution."""
+    b = pkg.scenes.c3_scene().buffers(native=pkg.ptmi.NativeHost())
+    assert b["triangles"].size // 24 == 871414 and b["bvh"].size // 12 == 2 * 871414 - 1
+    ctx.upload_scene(b)
+    view = cornell_view(pkg)
+    for stack in (24, 20):  # 20 = the reference's STACK_SIZE: the Q7 abort is live on a depth-20 tree
+        ctx.set_params(max_bounces=8, stack_size=stack)
+        ctx.resize(256, 144)
+        ctx.reset_stats()
+        ctx.set_counters(True)
+        ctx.render(view, 1, 2)
+        got = ctx.read_framebuffer()
+        st = ctx.stats()
+        ctx.set_counters(False)
+        want, ost = oracle.render(b, 256, 144, view, 1, 2, max_bounces=8, stack_size=stack)
+        assert_same_bits(got, want, "c3 stack %d" % stack)
+        for k in ("rays", "node_visits", "tri_tests", "quad_tests", "mat_fetches"):
+            assert st[k] == ost[k], (stack, k)

@@ -179,3 +179,65 @@ def golden_buffers(name):
         else:
             out[k] = np.zeros(0, np.int32 if k == "meshes" else np.float32)
     return out
+
+
+# ----------------------------------------------------------------------------- procedural stand-ins
+def _pcg_floats(seed, n):
+    """n draws of the reference's PCG stream (shaders/common.wgsl:7-12) in numpy — the generator's only randomness."""
+    out = np.empty(n, np.float64)
+    s = np.uint64(seed)
+    m32 = np.uint64(0xFFFFFFFF)
+    for i in range(n):
+        s = (s * np.uint64(747796405) + np.uint64(2891336453)) & m32
+        w = (((s >> ((s >> np.uint64(28)) + np.uint64(4))) ^ s) * np.uint64(277803737)) & m32
+        out[i] = float((w >> np.uint64(22)) ^ w) / 4294967296.0
+    return out
+
+
+def dragon_class_mesh(n_tris=871414, seed=1):
+    """Deterministic stand-in for stanfordDragon.obj (absent from the container, .MISSING_LARGE_BLOBS): a displaced
+    (2,3) torus-knot tube tessellated to EXACTLY n_tris triangles, smooth per-vertex normals, longest extent 1.
+    Returns the ObjReader layout {vertices, normals} (9 floats per triangle each)."""
+    quads = (n_tris + 1) // 2
+    nv = max(8, int(round(math.sqrt(quads / 2.0))))  # around the tube
+    nu = (quads + nv - 1) // nv                      # along the knot
+    r = _pcg_floats(seed, 24)
+    u = np.linspace(0, 2 * math.pi, nu, endpoint=False)[:, None]
+    v = np.linspace(0, 2 * math.pi, nv, endpoint=False)[None, :]
+    p, q = 2.0, 3.0
+    cu = np.concatenate([(2 + np.cos(q * u)) * np.cos(p * u), (2 + np.cos(q * u)) * np.sin(p * u), np.sin(q * u)], axis=1)  # (nu,3)
+    du = 2 * math.pi / nu
+    t = np.roll(cu, -1, 0) - np.roll(cu, 1, 0)
+    t /= np.linalg.norm(t, axis=1, keepdims=True)
+    ref = np.array([0.0, 0.0, 1.0])
+    n1 = np.cross(t, ref)
+    n1 /= np.linalg.norm(n1, axis=1, keepdims=True)
+    n2 = np.cross(t, n1)
+    rad = 0.45 * (1.0 + sum(0.06 * (0.5 + r[3 * k]) * np.sin((k + 2) * (3 * u + 2 * v) * (1 if k % 2 else -1) + 6.283 * r[3 * k + 1]) * np.cos((k + 1) * v + 6.283 * r[3 * k + 2]) for k in range(6)))
+    P = cu[:, None, :] + rad[..., None] * (np.cos(v)[..., None] * n1[:, None, :] + np.sin(v)[..., None] * n2[:, None, :])  # (nu,nv,3)
+    lo, hi = P.reshape(-1, 3).min(0), P.reshape(-1, 3).max(0)
+    P = (P - (lo + hi) / 2) / (hi - lo).max()
+    du_ = np.roll(P, -1, 0) - np.roll(P, 1, 0)
+    dv_ = np.roll(P, -1, 1) - np.roll(P, 1, 1)
+    N = np.cross(du_, dv_)
+    N /= np.linalg.norm(N, axis=2, keepdims=True)
+    i0 = np.arange(nu)[:, None]
+    j0 = np.arange(nv)[None, :]
+    i1, j1 = (i0 + 1) % nu, (j0 + 1) % nv
+
+    def tri(a, b, c):
+        return np.stack([a, b, c], axis=2)  # (nu,nv,3 verts,3)
+
+    def grid(A):
+        return tri(A[i0, j0], A[i1, j0], A[i1, j1]), tri(A[i0, j0], A[i1, j1], A[i0, j1])
+
+    (Pa, Pb), (Na, Nb) = grid(P), grid(N)
+    V = np.stack([Pa, Pb], axis=2).reshape(-1, 9)[:n_tris]
+    Nn = np.stack([Na, Nb], axis=2).reshape(-1, 9)[:n_tris]
+    return {"vertices": V.astype(np.float32).reshape(-1), "normals": Nn.astype(np.float32).reshape(-1)}
+
+
+def c3_scene(n_tris=871414, seed=1):
+    """BASELINE configs[2]: Cornell walls/light + dragon-class mesh with the reference's dragon transform
+    (lib/scene.js:216-220: scale 1.1, rotate pi/4 about y, translate (0.65,-0.64,0)) and dragonMat."""
+    return mesh_scene(dragon_class_mesh(n_tris, seed), scale=(1.1, 1.1, 1.1), rotate=(math.pi / 4, [0, 1, 0]), translate=(0.65, -0.64, 0))
