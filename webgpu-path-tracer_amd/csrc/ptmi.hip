@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -71,7 +72,8 @@ struct ptmi_ctx {
 
   size_t path_cap = 0;
   bool pixsum_alloc = false;
-  DBuf d_ray, d_thr, d_acc, d_pixsum, d_rng, d_hit, d_hitmat, d_q0, d_q1, d_ctl, d_totals, d_scratch;
+  DBuf d_ray, d_thr, d_acc, d_pixsum, d_rng, d_hit, d_hitmat, d_q0, d_q1, d_ctl, d_totals, d_scratch, d_chunk;
+  int traversal_mode = 0;  // 0 auto, 1 while-while, 2 flat
   int ctl_cap = 0;
 
   bool counters = false, timing = false;
@@ -398,15 +400,39 @@ uint32_t chunk_grid(const ptmi_ctx* c, uint32_t max_items, int blocks_per_cu) {
   return std::max<uint32_t>(1, std::min<uint32_t>(chunks, (uint32_t)c->num_cus * (uint32_t)blocks_per_cu));
 }
 
-void launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t* queue, uint32_t max_items) {
+// The digests of a scene that fits the L2s (4 MB per XCD) are served from cache: traversal is VALU bound and the
+// while-while variant wins; beyond that every visit is a trip to Infinity Cache / HBM and the flat variant wins.
+bool use_flat(const ptmi_ctx* c) {
+  if (c->traversal_mode == 1) return false;
+  if (c->traversal_mode == 2) return true;
+  return (c->d_pairs.cap + c->d_pretri.cap) > (size_t)(3u << 20);
+}
+
+int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t* queue, uint32_t max_items) {
   int sa = stack_alloc_for(c);
   size_t lds = (size_t)sa * 2 * kBlock * sizeof(int);  // two words per stack entry
   uint32_t grid = chunk_grid(c, max_items, 6);
+  const size_t per_block = (size_t)kChunk * (4 + 2 + 2 + 2);
+  HIP_TRY(c, c->d_chunk.ensure((size_t)c->num_cus * 6 * per_block));
+  ChunkScratch G;
+  const size_t nb = (size_t)c->num_cus * 6;
+  G.pid = c->d_chunk.as<uint32_t>();
+  G.mat = reinterpret_cast<uint16_t*>(G.pid + nb * kChunk);
+  G.list = G.mat + nb * kChunk;
+  G.key = G.list + nb * kChunk;
   unsigned long long* tot = c->d_totals.as<unsigned long long>();
-  if (c->counters)
-    hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(kBlock), lds, c->stream, c->S, P, ctl, queue, c->prm.stack_size, sa, grid, tot);
-  else
-    hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(kBlock), lds, c->stream, c->S, P, ctl, queue, c->prm.stack_size, sa, grid, tot);
+  const bool flat = use_flat(c);
+#define PTMI_LAUNCH_ISECT(CNT, FL) \
+  hipLaunchKernelGGL((k_intersect<CNT, FL>), dim3(grid), dim3(kBlock), lds, c->stream, c->S, P, ctl, queue, G, c->prm.stack_size, sa, grid, tot)
+  if (c->counters) {
+    if (flat) PTMI_LAUNCH_ISECT(true, true);
+    else PTMI_LAUNCH_ISECT(true, false);
+  } else {
+    if (flat) PTMI_LAUNCH_ISECT(false, true);
+    else PTMI_LAUNCH_ISECT(false, false);
+  }
+#undef PTMI_LAUNCH_ISECT
+  return PTMI_OK;
 }
 
 int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames, int reset_first) {
@@ -461,7 +487,8 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   for (int s = 0; s < n_steps; s++) {
     {
       ScopedSpan sp(c, T_INTERSECT);
-      launch_intersect(c, P, ctl + s, q[s & 1], total);
+      int lr = launch_intersect(c, P, ctl + s, q[s & 1], total);
+      if (lr) return lr;
     }
     {
       ScopedSpan sp(c, T_SHADE);
@@ -549,6 +576,7 @@ int ptmi_create(ptmi_ctx** out, int device_id) {
   c->device = device_id;
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   ptmi_default_params(&c->prm);
+  if (const char* tm = getenv("PTMI_TRAVERSAL")) c->traversal_mode = atoi(tm);  // 1 = while-while, 2 = flat (tuning aid)
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     delete c;
@@ -566,7 +594,7 @@ void ptmi_destroy(ptmi_ctx* c) {
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (DBuf* b : {&c->d_spheres, &c->d_sphere_info, &c->d_quads, &c->d_quad_mat, &c->d_tris, &c->d_pretri, &c->d_meshes, &c->d_xforms,
                   &c->d_mats, &c->d_pairs, &c->d_leaf_table, &c->d_fb_own, &c->d_ray, &c->d_thr, &c->d_acc, &c->d_pixsum, &c->d_rng, &c->d_hit, &c->d_hitmat,
-                  &c->d_q0, &c->d_q1, &c->d_ctl, &c->d_totals, &c->d_scratch})
+                  &c->d_q0, &c->d_q1, &c->d_chunk, &c->d_ctl, &c->d_totals, &c->d_scratch})
     b->release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -803,7 +831,8 @@ int ptmi_trace(ptmi_ctx* c, size_t n, const float* rays6, uint32_t* rng_inout, p
   HIP_TRY(c, hipMemcpyAsync(P.rng, rng.data(), n * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->d_q0.p, ident.data(), n * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(ctl, &ctl0, sizeof ctl0, hipMemcpyHostToDevice, c->stream));
-  launch_intersect(c, P, ctl, c->d_q0.as<uint32_t>(), (uint32_t)n);
+  r = launch_intersect(c, P, ctl, c->d_q0.as<uint32_t>(), (uint32_t)n);
+  if (r) return r;
   HIP_TRY(c, c->d_scratch.ensure(n * sizeof(HitOut)));
   hipLaunchKernelGGL(k_resolve_hits, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->S, P, (uint32_t)n, c->d_scratch.as<HitOut>());
   HIP_TRY(c, hipGetLastError());

@@ -355,63 +355,164 @@ DEV void visit_leaf(const DevScene& S, uint32_t ref, f3 o, f3 d, ObjRay& orr, Cl
 // reference would pop and re-test it against the then-current closest_so_far, the outcome
 //     min(closest, tb) > ts   ==   isnan(closest) ? B : (A && closest > ts)
 // (A = tb > ts || isnan(tb), B = tb > ts; min drops NaNs, ptmi_math.h) is evaluated from the stack
-// entry alone.  `stk` is this lane's column of the LDS stack: word w of entry e lives at stk[(2e+w)*64].
-template <bool COUNT>
-DEV void traverse_bvh(const DevScene& S, f3 o, f3 d, int stack_size, int* __restrict__ stk, Closest& c, Counters& cn) {
-  if (S.n_nodes <= 0) return;  // no triangle geometry (an empty binding cannot exist in WebGPU)
-  const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+// entry alone.
+//
+// The traversal is a per-lane state machine so that a wave can interleave rays (lane refill):
+//   cur     = pair index of an inner node whose box has passed, T_POP (take the next stack entry) or T_DONE
+//   pending = ref of a leaf whose box has passed and whose triangles are still to be tested, 0 = none
+// One `trav_step` performs one reference visit (an inner node's near child, or one popped entry).  Leaves are
+// postponed into `pending` so that all lanes of a wave test triangles together (while-while traversal).
+// `stk` is this lane's column of the LDS stack: word w of entry e lives at stk[(2e+w)*64].
+constexpr uint32_t T_DONE = 0xffffffffu, T_POP = 0xfffffffeu;
+
+struct Trav {
+  f3 o, d, inv;
   ObjRay orr;
-  orr.mesh = -1;
-  orr.o = orr.d = mk3(0, 0, 0);
-  if (COUNT) cn.node_visits++;
-  if (!hit_aabb(S.root_lo, S.root_hi, c.t, o, inv)) return;
-  const uint32_t root = __float_as_uint(S.root_lo.w);
-  if (root & REF_LEAF) {
-    visit_leaf<COUNT>(S, root, o, d, orr, c, cn);
+  Closest c;
+  uint32_t cur, pending;
+  int sp;
+  uint32_t negmask;  // bit a = (d[a] < 0)
+};
+
+template <bool COUNT>
+DEV void trav_step(const DevScene& S, int stack_size, int* __restrict__ stk, Trav& t, Counters& cn) {
+  if (t.cur == T_POP) {
+    if (t.sp == 0) {
+      t.cur = T_DONE;
+      return;
+    }
+    t.sp--;
+    const uint32_t e = (uint32_t)stk[(2 * t.sp) * 64];
+    const float ts = __int_as_float(stk[(2 * t.sp + 1) * 64]);
+    if (COUNT) cn.node_visits++;
+    const float ct = t.c.t;
+    const bool pass = (ct != ct) ? ((e & REF_B) != 0u) : (((e & REF_A) != 0u) && (ct > ts));
+    if (pass) {
+      if (e & REF_LEAF) t.pending = e;  // cur stays T_POP: after the leaf the reference pops again
+      else t.cur = e & REF_IDX;
+    }
     return;
   }
-  int sp = 0;
-  uint32_t cur = root & REF_IDX;
-  while (true) {
-    const float4* pr = S.pairs + 4 * (size_t)cur;
-    const float4 f0 = pr[0], f1 = pr[1], f2 = pr[2], f3v = pr[3];
-    float tsL, tbL, tsR, tbR;
-    slab(f0, f1, o, inv, tsL, tbL);
-    slab(f2, f3v, o, inv, tsR, tbR);
-    const int axis = __float_as_int(f2.w);
-    const float dax = (axis == 0) ? d.x : ((axis == 1) ? d.y : d.z);
-    const bool neg = dax < 0;  // hitRay.wgsl:80: push the left child, go right
-    const uint32_t refL = __float_as_uint(f0.w), refR = __float_as_uint(f1.w);
-    const uint32_t nearRef = neg ? refR : refL;
-    uint32_t farRef = neg ? refL : refR;
-    const float tsN = neg ? tsR : tsL, tbN = neg ? tbR : tbL;
-    const float tsF = neg ? tsL : tsR, tbF = neg ? tbL : tbR;
-    const bool fB = tbF > tsF;
-    const bool fA = fB || (tbF != tbF);
-    farRef |= (fA ? REF_A : 0u) | (fB ? REF_B : 0u);
-    stk[(2 * sp) * 64] = (int)farRef;
-    stk[(2 * sp + 1) * 64] = __float_as_int(tsF);
-    sp++;
-    if (sp >= stack_size) return;  // hitRay.wgsl:106-109 (Q7)
-    if (COUNT) cn.node_visits++;
-    uint32_t next = 0xffffffffu;
-    if (ptm_min(c.t, tbN) > tsN) {
-      if (nearRef & REF_LEAF) visit_leaf<COUNT>(S, nearRef, o, d, orr, c, cn);
-      else next = nearRef;
-    }
-    while (next == 0xffffffffu) {
-      if (sp == 0) return;
-      sp--;
-      const uint32_t e = (uint32_t)stk[(2 * sp) * 64];
-      const float ts = __int_as_float(stk[(2 * sp + 1) * 64]);
+  const float4* pr = S.pairs + 4 * (size_t)t.cur;
+  const float4 f0 = pr[0], f1 = pr[1], f2 = pr[2], f3v = pr[3];
+  float tsL, tbL, tsR, tbR;
+  slab(f0, f1, t.o, t.inv, tsL, tbL);
+  slab(f2, f3v, t.o, t.inv, tsR, tbR);
+  const int axis = __float_as_int(f2.w);
+  // hitRay.wgsl:80 `ray.dir[axis] < 0`: push the left child, go right.  The three sign tests are made once per
+  // ray (negmask); indexing t.d by `axis` here would force the whole struct into scratch memory.
+  const bool neg = ((t.negmask >> axis) & 1u) != 0u;
+  const uint32_t refL = __float_as_uint(f0.w), refR = __float_as_uint(f1.w);
+  const uint32_t nearRef = neg ? refR : refL;
+  uint32_t farRef = neg ? refL : refR;
+  const float tsN = neg ? tsR : tsL, tbN = neg ? tbR : tbL;
+  const float tsF = neg ? tsL : tsR, tbF = neg ? tbL : tbR;
+  const bool fB = tbF > tsF;
+  const bool fA = fB || (tbF != tbF);
+  farRef |= (fA ? REF_A : 0u) | (fB ? REF_B : 0u);
+  stk[(2 * t.sp) * 64] = (int)farRef;
+  stk[(2 * t.sp + 1) * 64] = __float_as_int(tsF);
+  t.sp++;
+  if (t.sp >= stack_size) {  // hitRay.wgsl:106-109 (Q7): the whole traversal stops
+    t.cur = T_DONE;
+    return;
+  }
+  if (COUNT) cn.node_visits++;
+  t.cur = T_POP;
+  if (ptm_min(t.c.t, tbN) > tsN) {
+    if (nearRef & REF_LEAF) t.pending = nearRef;
+    else t.cur = nearRef;
+  }
+}
+
+// Triangle test on an already fetched pretri record (same arithmetic as hit_triangle).
+template <bool COUNT>
+DEV void tri_record_test(const DevScene& S, int k, float4 t0, float4 t1, float4 t2, float4 t3, Trav& t, Counters& cn) {
+  int mesh = __float_as_int(t0.w);
+  if (mesh != t.orr.mesh) obj_ray_for(S, mesh, t.o, t.d, t.orr);
+  if (COUNT) cn.tri_tests++;
+  f3 A = mk3(t0), AB = mk3(t1), AC = mk3(t2), N = mk3(t3);
+  float det = -dot3(t.orr.d, N);
+  if (ptm_abs(det) < kTmin) return;
+  f3 ao = t.orr.o - A;
+  f3 dao = cross3(ao, t.orr.d);
+  float invDet = 1.0f / det;
+  float dst = dot3(ao, N) * invDet;
+  float u = dot3(AC, dao) * invDet;
+  float v = -dot3(AB, dao) * invDet;
+  float w = 1.0f - u - v;
+  if (dst < kTmin || dst > t.c.t || u < kTmin || v < kTmin || w < kTmin) return;
+  t.c.t = dst;
+  t.c.u = u;
+  t.c.v = v;
+  t.c.prim = (K_TRI << 28) | (uint32_t)k;
+  t.c.mat = S.meshes[mesh].w;
+  if (COUNT) cn.mat_fetches++;
+}
+
+// Flat traversal iteration for the latency-bound regime (BVH larger than the caches): every lane fetches
+// exactly ONE 64-byte record — the pair record of its inner node or the pretri record of its pending
+// triangle, both 4 x float4 — so the wave pays one memory round trip per iteration and every lane advances by
+// one reference visit.  Failing stack entries are popped right away (LDS only), so that the next iteration
+// again has a record to fetch.  Visit order and outcomes are those of trav_step/visit_leaf.
+template <bool COUNT>
+DEV void trav_flat_iter(const DevScene& S, int stack_size, int* __restrict__ stk, Trav& t, Counters& cn) {
+  const bool leaf = t.pending != 0u;
+  const bool simple_leaf = leaf && !(t.pending & REF_MULTI);
+  if (leaf && !simple_leaf) {  // prim_count != 1 (external BVHs): rare, not unified
+    visit_leaf<COUNT>(S, t.pending, t.o, t.d, t.orr, t.c, cn);
+    t.pending = 0u;
+  } else if (leaf || t.cur < T_POP) {
+    const float4* rec = simple_leaf ? (S.pretri + 4 * (size_t)(t.pending & REF_IDX)) : (S.pairs + 4 * (size_t)t.cur);
+    const float4 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3v = rec[3];
+    if (simple_leaf) {
+      tri_record_test<COUNT>(S, (int)(t.pending & REF_IDX), f0, f1, f2, f3v, t, cn);
+      t.pending = 0u;
+    } else {
+      float tsL, tbL, tsR, tbR;
+      slab(f0, f1, t.o, t.inv, tsL, tbL);
+      slab(f2, f3v, t.o, t.inv, tsR, tbR);
+      const int axis = __float_as_int(f2.w);
+      const bool neg = ((t.negmask >> axis) & 1u) != 0u;
+      const uint32_t refL = __float_as_uint(f0.w), refR = __float_as_uint(f1.w);
+      const uint32_t nearRef = neg ? refR : refL;
+      uint32_t farRef = neg ? refL : refR;
+      const float tsN = neg ? tsR : tsL, tbN = neg ? tbR : tbL;
+      const float tsF = neg ? tsL : tsR, tbF = neg ? tbL : tbR;
+      const bool fB = tbF > tsF;
+      const bool fA = fB || (tbF != tbF);
+      farRef |= (fA ? REF_A : 0u) | (fB ? REF_B : 0u);
+      stk[(2 * t.sp) * 64] = (int)farRef;
+      stk[(2 * t.sp + 1) * 64] = __float_as_int(tsF);
+      t.sp++;
+      if (t.sp >= stack_size) {  // Q7
+        t.cur = T_DONE;
+        return;
+      }
       if (COUNT) cn.node_visits++;
-      const bool pass = (c.t != c.t) ? ((e & REF_B) != 0u) : (((e & REF_A) != 0u) && (c.t > ts));
-      if (pass) {
-        if (e & REF_LEAF) visit_leaf<COUNT>(S, e, o, d, orr, c, cn);
-        else next = e & REF_IDX;
+      t.cur = T_POP;
+      if (ptm_min(t.c.t, tbN) > tsN) {
+        if (nearRef & REF_LEAF) t.pending = nearRef;
+        else t.cur = nearRef;
       }
     }
-    cur = next;
+  }
+  // pop until an entry passes or the stack is empty (LDS only)
+  while (t.cur == T_POP && t.pending == 0u) {
+    if (t.sp == 0) {
+      t.cur = T_DONE;
+      break;
+    }
+    t.sp--;
+    const uint32_t e = (uint32_t)stk[(2 * t.sp) * 64];
+    const float ts = __int_as_float(stk[(2 * t.sp + 1) * 64]);
+    if (COUNT) cn.node_visits++;
+    const float ct = t.c.t;
+    const bool pass = (ct != ct) ? ((e & REF_B) != 0u) : (((e & REF_A) != 0u) && (ct > ts));
+    if (pass) {
+      if (e & REF_LEAF) t.pending = e;
+      else t.cur = e & REF_IDX;
+    }
   }
 }
 

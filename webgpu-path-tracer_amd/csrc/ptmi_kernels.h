@@ -56,24 +56,71 @@ DEV int bin_of(const DevScene& S, uint32_t prim, int mat) {
   return (ty == 0.0f) ? BIN_LAMBERTIAN : (ty == 1.0f) ? BIN_MIRROR : (ty == 2.0f) ? BIN_GLASS : (ty == 3.0f) ? BIN_ISOTROPIC : BIN_OTHER;
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ queue, int stack_size,
-                                                      int stack_alloc, uint32_t target_blocks, unsigned long long* __restrict__ totals) {
+// Rank of this lane's entry within its material bin for the current chunk (counting sort, pass 1).
+// Must be called from wave-uniform control flow; lanes without an entry pass bin = -1.
+DEV uint32_t bin_rank(int bin, uint32_t* s_cnt) {
+  uint32_t rank = 0;
+#pragma unroll
+  for (int b = 0; b < NUM_BINS; b++) {
+    const bool mine = (bin == b);
+    const uint64_t mk = __ballot(mine);
+    if (mk) {
+      const int leader = __ffsll((unsigned long long)mk) - 1;
+      uint32_t bb = 0;
+      if (lane_id() == leader) bb = atomicAdd(&s_cnt[b], (uint32_t)__popcll(mk));
+      bb = (uint32_t)__shfl((int)bb, leader, 64);
+      if (mine) rank = bb + lanes_below(mk);
+    }
+  }
+  return rank;
+}
+
+// A wave refills its idle lanes from the chunk's BVH list once this many lanes are idle (or all are).
+constexpr int kRefillThreshold = 16;
+
+// Per-block bookkeeping of the chunk being processed lives in a global scratch slab (L2 resident, touched
+// twice per ray) so that LDS is left to the traversal stacks: on a depth-20 tree the stacks alone are 40 KB
+// per 256-thread block and LDS decides how many waves a CU can hold.
+struct ChunkScratch {
+  uint32_t* pid;   // [grid][kChunk] path id of entry j
+  uint16_t* mat;   // [grid][kChunk] effective material of the final hit, 0xffff = miss
+  uint16_t* list;  // [grid][kChunk] entries that traverse the BVH
+  uint16_t* key;   // [grid][kChunk] bin | rank << 3
+};
+
+// hitScene for one chunk of the ray queue, in three phases:
+//   1  every thread takes rays tid, tid+256, ...: spheres, quads and the ROOT box test (hitRay.wgsl:6-54) —
+//      coherent, data in SGPRs.  Rays that do not enter the root box are final; the others are compacted
+//      into a list.
+//   2  persistent lanes: each lane runs the traversal state machine on one listed ray; a wave refills idle
+//      lanes from the list (ballot + one LDS atomic) whenever kRefillThreshold lanes have finished, so
+//      short rays do not leave lanes idle while the longest ray of a wave finishes.
+//      FLAT = false (BVH fits the caches, VALU bound): while-while — inner steps and triangle tests run in
+//      separate loops so each runs with as many lanes as possible.
+//      FLAT = true (large BVH, latency bound): one 64-byte record fetch per lane per iteration.
+//   3  counting sort of the chunk by material class (ballot ranks), written back in place.
+template <bool COUNT, bool FLAT>
+__global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ queue, ChunkScratch G,
+                                                      int stack_size, int stack_alloc, uint32_t target_blocks, unsigned long long* __restrict__ totals) {
   extern __shared__ int lds_stack[];
-  __shared__ uint32_t s_pid[kChunk];
-  __shared__ uint16_t s_key[kChunk];  // bin | rank-within-bin << 3
   __shared__ uint32_t s_cnt[NUM_BINS + 2];
-  __shared__ uint32_t s_chunk, s_next;
+  __shared__ uint32_t s_chunk, s_list_n, s_list_next;
   const int lane = lane_id();
   int* stk = lds_stack + (threadIdx.x >> 6) * (stack_alloc * 2 * 64) + lane;
+  uint32_t* g_pid = G.pid + (size_t)blockIdx.x * kChunk;
+  uint16_t* g_mat = G.mat + (size_t)blockIdx.x * kChunk;
+  uint16_t* g_list = G.list + (size_t)blockIdx.x * kChunk;
+  uint16_t* g_key = G.key + (size_t)blockIdx.x * kChunk;
   const uint32_t n = ctl->n_rays;
   const uint32_t csz = chunk_size_for(n, target_blocks);
+  const bool have_bvh = S.n_nodes > 0;
   Counters cn = {0, 0, 0, 0, 0};
 
   while (true) {
     if (threadIdx.x == 0) {
       s_chunk = atomicAdd(&ctl->head_i, 1u);
-      s_next = 0;
+      s_list_n = 0;
+      s_list_next = 0;
     }
     if (threadIdx.x < NUM_BINS) s_cnt[threadIdx.x] = 0;
     __syncthreads();
@@ -81,17 +128,14 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, Paths P, StepC
     if (base >= n) break;
     const uint32_t m = min(csz, n - base);
 
-    while (true) {
-      uint32_t sub = 0;
-      if (lane == 0) sub = atomicAdd(&s_next, 64u);
-      sub = (uint32_t)__builtin_amdgcn_readfirstlane((int)sub);
-      if (sub >= m) break;
-      const uint32_t j = sub + lane;
+    // ---- phase 1 ----
+    for (uint32_t j0 = (threadIdx.x & ~63u); j0 < m; j0 += kBlock) {
+      const uint32_t j = j0 + lane;
       const bool active = j < m;
-      int bin = -1;
-      uint32_t pid = 0;
+      bool to_bvh = false;
       if (active) {
-        pid = queue[base + j];
+        const uint32_t pid = queue[base + j];
+        g_pid[j] = pid;
         float4 r0 = P.ray[2 * (size_t)pid], r1 = P.ray[2 * (size_t)pid + 1];
         f3 o = mk3(r0), d = mk3(r1);
         Closest c;
@@ -106,32 +150,131 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, Paths P, StepC
           if (rng != rng0) P.rng[pid] = rng;
         }
         hit_quads<COUNT>(S, o, d, c, cn);
-        traverse_bvh<COUNT>(S, o, d, stack_size, stk, c, cn);
-        P.hit[pid] = make_float4(c.t, c.u, c.v, __uint_as_float(c.prim));
-        if ((c.prim >> 28) != K_NONE) P.hitmat[pid] = (uint32_t)c.mat;
-        bin = bin_of(S, c.prim, c.mat);
-      }
-      // rank of every entry within its bin for this chunk (counting sort, pass 1)
-      uint32_t rank = 0;
-#pragma unroll
-      for (int b = 0; b < NUM_BINS; b++) {
-        const bool mine = (bin == b);
-        const uint64_t mk = __ballot(mine);
-        if (mk) {
-          const int leader = __ffsll((unsigned long long)mk) - 1;
-          uint32_t bb = 0;
-          if (lane == leader) bb = atomicAdd(&s_cnt[b], (uint32_t)__popcll(mk));
-          bb = (uint32_t)__shfl((int)bb, leader, 64);
-          if (mine) rank = bb + lanes_below(mk);
+        if (have_bvh) {
+          if (COUNT) cn.node_visits++;
+          const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+          to_bvh = hit_aabb(S.root_lo, S.root_hi, c.t, o, inv);
         }
+        const bool hit = (c.prim >> 28) != K_NONE;
+        P.hit[pid] = make_float4(c.t, c.u, c.v, __uint_as_float(c.prim));
+        if (hit) P.hitmat[pid] = (uint32_t)c.mat;
+        g_mat[j] = hit ? (uint16_t)c.mat : (uint16_t)0xffffu;
       }
-      if (active) {
-        s_pid[j] = pid;
-        s_key[j] = (uint16_t)((uint32_t)bin | (rank << 3));
+      const uint64_t lm = __ballot(to_bvh);
+      if (lm) {
+        const int leader = __ffsll((unsigned long long)lm) - 1;
+        uint32_t lb = 0;
+        if (lane == leader) lb = atomicAdd(&s_list_n, (uint32_t)__popcll(lm));
+        lb = (uint32_t)__shfl((int)lb, leader, 64);
+        if (to_bvh) g_list[lb + lanes_below(lm)] = (uint16_t)j;
+      }
+    }
+    __syncthreads();  // also makes this block's global scratch writes visible to its own waves (same CU)
+
+    // ---- phase 2 ----
+    const uint32_t list_n = s_list_n;
+    if (list_n > 0) {
+      bool has = false;
+      uint32_t myj = 0, mypid = 0;
+      Trav t;
+      t.cur = T_DONE;
+      t.pending = 0;
+      t.sp = 0;
+      t.negmask = 0;
+      t.o = t.d = t.inv = mk3(0, 0, 0);
+      t.orr.mesh = -1;
+      t.orr.o = t.orr.d = mk3(0, 0, 0);
+      t.c.t = 0.0f, t.c.u = t.c.v = 0.0f, t.c.prim = K_NONE, t.c.mat = 0;
+      const uint32_t root = __float_as_uint(S.root_lo.w);
+      for (;;) {
+        // retire finished rays (stores only: nothing here waits on memory)
+        if (has && t.cur == T_DONE && t.pending == 0u) {
+          const bool hit = (t.c.prim >> 28) != K_NONE;
+          P.hit[mypid] = make_float4(t.c.t, t.c.u, t.c.v, __uint_as_float(t.c.prim));
+          if (hit) P.hitmat[mypid] = (uint32_t)t.c.mat;
+          g_mat[myj] = hit ? (uint16_t)t.c.mat : (uint16_t)0xffffu;
+          has = false;
+        }
+        // refill idle lanes
+        uint64_t hm = __ballot(has);
+        int nact = __popcll(hm);
+        bool more = s_list_next < list_n;
+        if (more && (64 - nact) >= (nact == 0 ? 1 : kRefillThreshold)) {
+          const uint64_t idle = ~hm;
+          const int leader = __ffsll((unsigned long long)idle) - 1;
+          uint32_t lb = 0;
+          if (lane == leader) lb = atomicAdd(&s_list_next, (uint32_t)(64 - nact));
+          lb = (uint32_t)__shfl((int)lb, leader, 64);
+          if (!has) {
+            const uint32_t k = lb + lanes_below(idle);
+            if (k < list_n) {
+              myj = g_list[k];
+              mypid = g_pid[myj];
+              float4 r0 = P.ray[2 * (size_t)mypid], r1 = P.ray[2 * (size_t)mypid + 1];
+              float4 h = P.hit[mypid];
+              const uint16_t m16 = g_mat[myj];
+              t.o = mk3(r0);
+              t.d = mk3(r1);
+              t.inv = mk3(1.0f / t.d.x, 1.0f / t.d.y, 1.0f / t.d.z);
+              t.negmask = (t.d.x < 0 ? 1u : 0u) | (t.d.y < 0 ? 2u : 0u) | (t.d.z < 0 ? 4u : 0u);
+              t.c.t = h.x, t.c.u = h.y, t.c.v = h.z, t.c.prim = __float_as_uint(h.w);
+              t.c.mat = (m16 != 0xffffu) ? (int)m16 : 0;
+              t.orr.mesh = -1;
+              t.sp = 0;
+              if (root & REF_LEAF) {
+                t.pending = root;
+                t.cur = T_POP;
+              } else {
+                t.pending = 0;
+                t.cur = root & REF_IDX;
+              }
+              has = true;
+            }
+          }
+          hm = __ballot(has);
+          nact = __popcll(hm);
+          more = s_list_next < list_n;
+        }
+        if (nact == 0) break;
+        // traversal burst: until enough lanes have finished to make a refill worthwhile
+        const int min_working = more ? (64 - kRefillThreshold + 1) : 1;
+        int working;
+        if (FLAT) {
+          do {
+            if (has && !(t.cur == T_DONE && t.pending == 0u)) trav_flat_iter<COUNT>(S, stack_size, stk, t, cn);
+            working = __popcll(__ballot(has && !(t.cur == T_DONE && t.pending == 0u)));
+          } while (working >= min_working);
+        } else {
+          do {
+            while (has && t.cur != T_DONE && t.pending == 0u) trav_step<COUNT>(S, stack_size, stk, t, cn);
+            if (has && t.pending != 0u) {
+              visit_leaf<COUNT>(S, t.pending, t.o, t.d, t.orr, t.c, cn);
+              t.pending = 0u;
+            }
+            working = __popcll(__ballot(has && t.cur != T_DONE));
+          } while (working >= min_working);
+        }
       }
     }
     __syncthreads();
-    // pass 2: scatter the chunk back IN PLACE, grouped by bin -> the shade kernel sees bin-uniform waves
+
+    // ---- phase 3: counting sort by material class, scattered back IN PLACE -> bin-uniform shade waves
+    for (uint32_t j0 = (threadIdx.x & ~63u); j0 < m; j0 += kBlock) {
+      const uint32_t j = j0 + lane;
+      int bin = -1;
+      if (j < m) {
+        const uint16_t m16 = g_mat[j];
+        if (m16 == 0xffffu) {
+          bin = BIN_MISS;
+        } else {
+          const float ty = S.mats[4 * (int)m16 + 3].z;
+          bin = (ty == 0.0f) ? BIN_LAMBERTIAN : (ty == 1.0f) ? BIN_MIRROR : (ty == 2.0f) ? BIN_GLASS : (ty == 3.0f) ? BIN_ISOTROPIC : BIN_OTHER;
+        }
+      }
+      const uint32_t rank = bin_rank(bin, s_cnt);
+      if (j < m) g_key[j] = (uint16_t)((uint32_t)bin | (rank << 3));
+    }
+    __syncthreads();
     uint32_t off[NUM_BINS];
     uint32_t run = 0;
 #pragma unroll
@@ -140,12 +283,12 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, Paths P, StepC
       run += s_cnt[b];
     }
     for (uint32_t j = threadIdx.x; j < m; j += kBlock) {
-      const uint32_t key = s_key[j];
+      const uint32_t key = g_key[j];
       const uint32_t b = key & 7u;
       uint32_t o = off[0];
 #pragma unroll
       for (int k = 1; k < NUM_BINS; k++) o = (b == (uint32_t)k) ? off[k] : o;
-      queue[base + o + (key >> 3)] = s_pid[j];
+      queue[base + o + (key >> 3)] = g_pid[j];
     }
     __syncthreads();
   }
