@@ -72,7 +72,7 @@ struct ptmi_ctx {
 
   size_t path_cap = 0;
   bool pixsum_alloc = false;
-  DBuf d_ray, d_thr, d_acc, d_pixsum, d_rng, d_hit, d_hitmat, d_q0, d_q1, d_ctl, d_totals, d_scratch, d_chunk;
+  DBuf d_ray, d_thr, d_acc, d_pixsum, d_rng, d_hit, d_hitmat, d_q0, d_q1, d_ctl, d_totals, d_scratch, d_bvhlist;
   int traversal_mode = 0;  // 0 auto, 1 while-while, 2 flat
   int ctl_cap = 0;
 
@@ -363,6 +363,7 @@ int ensure_paths(ptmi_ctx* c, size_t npaths, int n_ctl, bool need_pixsum) {
     HIP_TRY(c, c->d_hitmat.ensure(npaths * 4));
     HIP_TRY(c, c->d_q0.ensure(npaths * 4));
     HIP_TRY(c, c->d_q1.ensure(npaths * 4));
+    HIP_TRY(c, c->d_bvhlist.ensure(npaths * 4));
     c->path_cap = npaths;
     c->pixsum_alloc = false;
   }
@@ -400,38 +401,42 @@ uint32_t chunk_grid(const ptmi_ctx* c, uint32_t max_items, int blocks_per_cu) {
   return std::max<uint32_t>(1, std::min<uint32_t>(chunks, (uint32_t)c->num_cus * (uint32_t)blocks_per_cu));
 }
 
-// The digests of a scene that fits the L2s (4 MB per XCD) are served from cache: traversal is VALU bound and the
-// while-while variant wins; beyond that every visit is a trip to Infinity Cache / HBM and the flat variant wins.
-bool use_flat(const ptmi_ctx* c) {
-  if (c->traversal_mode == 1) return false;
-  if (c->traversal_mode == 2) return true;
-  return (c->d_pairs.cap + c->d_pretri.cap) > (size_t)(3u << 20);
+// Traversal variant.  Measured on MI355X (round 1): the flat variant (one 64-byte record fetch per lane per iteration)
+// beats while-while both on a cache-resident BVH (configs[1]: 8.95 vs 8.05 Grays/s) and on a 112 MB one
+// (configs[2]: 3.48 vs ~1.6 Grays/s), so it is the default; PTMI_TRAVERSAL=1 selects while-while for A/B runs.
+bool use_flat(const ptmi_ctx* c) { return c->traversal_mode != 1; }
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
 }
 
-int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t* queue, uint32_t max_items) {
-  int sa = stack_alloc_for(c);
-  size_t lds = (size_t)sa * 2 * kBlock * sizeof(int);  // two words per stack entry
-  uint32_t grid = chunk_grid(c, max_items, 6);
-  const size_t per_block = (size_t)kChunk * (4 + 2 + 2 + 2);
-  HIP_TRY(c, c->d_chunk.ensure((size_t)c->num_cus * 6 * per_block));
-  ChunkScratch G;
-  const size_t nb = (size_t)c->num_cus * 6;
-  G.pid = c->d_chunk.as<uint32_t>();
-  G.mat = reinterpret_cast<uint16_t*>(G.pid + nb * kChunk);
-  G.list = G.mat + nb * kChunk;
-  G.key = G.list + nb * kChunk;
+// hitScene for the step's queue: k_prims (coherent part + BVH list) then k_bvh (traversal).
+int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, const uint32_t* queue, uint32_t max_items) {
   unsigned long long* tot = c->d_totals.as<unsigned long long>();
+  uint32_t* list = c->d_bvhlist.as<uint32_t>();
+  const uint32_t pgrid = std::max<uint32_t>(1, std::min<uint32_t>((max_items + kChunk - 1) / kChunk, (uint32_t)c->num_cus * 8));
+  if (c->counters) hipLaunchKernelGGL(k_prims<true>, dim3(pgrid), dim3(kBlock), 0, c->stream, c->S, P, ctl, queue, list, tot);
+  else hipLaunchKernelGGL(k_prims<false>, dim3(pgrid), dim3(kBlock), 0, c->stream, c->S, P, ctl, queue, list, tot);
+  if (c->S.n_nodes <= 0) return PTMI_OK;
+  const int sa = stack_alloc_for(c);
+  const size_t lds = (size_t)sa * 2 * 64 * sizeof(int);  // one wave per block, two words per stack entry
   const bool flat = use_flat(c);
-#define PTMI_LAUNCH_ISECT(CNT, FL) \
-  hipLaunchKernelGGL((k_intersect<CNT, FL>), dim3(grid), dim3(kBlock), lds, c->stream, c->S, P, ctl, queue, G, c->prm.stack_size, sa, grid, tot)
+  // VGPR budget: flat variant <= 128 VGPRs (4 waves/SIMD), while-while <= 96 (5 waves/SIMD)
+  int waves_per_cu = (int)std::min<size_t>(flat ? 16 : 20, (size_t)(160 * 1024) / (lds + 64));
+  if (env_int("PTMI_WAVES_PER_CU", 0) > 0) waves_per_cu = env_int("PTMI_WAVES_PER_CU", 0);  // tuning aid; 0/unset = auto
+  const uint32_t want = (max_items + 63) / 64;
+  const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(want, (uint32_t)c->num_cus * (uint32_t)waves_per_cu));
+  const int thr = env_int("PTMI_REFILL", kRefillThreshold);
+#define PTMI_LAUNCH_BVH(CNT, FL) hipLaunchKernelGGL((k_bvh<CNT, FL>), dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, list, c->prm.stack_size, thr, tot)
   if (c->counters) {
-    if (flat) PTMI_LAUNCH_ISECT(true, true);
-    else PTMI_LAUNCH_ISECT(true, false);
+    if (flat) PTMI_LAUNCH_BVH(true, true);
+    else PTMI_LAUNCH_BVH(true, false);
   } else {
-    if (flat) PTMI_LAUNCH_ISECT(false, true);
-    else PTMI_LAUNCH_ISECT(false, false);
+    if (flat) PTMI_LAUNCH_BVH(false, true);
+    else PTMI_LAUNCH_BVH(false, false);
   }
-#undef PTMI_LAUNCH_ISECT
+#undef PTMI_LAUNCH_BVH
   return PTMI_OK;
 }
 
@@ -594,7 +599,7 @@ void ptmi_destroy(ptmi_ctx* c) {
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (DBuf* b : {&c->d_spheres, &c->d_sphere_info, &c->d_quads, &c->d_quad_mat, &c->d_tris, &c->d_pretri, &c->d_meshes, &c->d_xforms,
                   &c->d_mats, &c->d_pairs, &c->d_leaf_table, &c->d_fb_own, &c->d_ray, &c->d_thr, &c->d_acc, &c->d_pixsum, &c->d_rng, &c->d_hit, &c->d_hitmat,
-                  &c->d_q0, &c->d_q1, &c->d_chunk, &c->d_ctl, &c->d_totals, &c->d_scratch})
+                  &c->d_q0, &c->d_q1, &c->d_bvhlist, &c->d_ctl, &c->d_totals, &c->d_scratch})
     b->release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;

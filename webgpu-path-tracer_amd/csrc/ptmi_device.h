@@ -118,9 +118,9 @@ struct Paths {
 
 struct StepCtl {
   uint32_t n_rays;  // entries in this step's ray queue
-  uint32_t head_i;  // next chunk for k_intersect
+  uint32_t n_bvh;   // entries of the BVH list (rays that entered the root box), written by k_prims
+  uint32_t head_b;  // next range of the BVH list for k_bvh
   uint32_t head_s;  // next chunk for k_shade
-  uint32_t pad;
 };
 
 struct RenderConst {

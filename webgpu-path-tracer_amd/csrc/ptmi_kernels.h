@@ -2,11 +2,12 @@
 //
 //   k_generate   one thread per (frame slot, owned pixel): seeds the RNG (main.wgsl:16), builds the
 //                camera ray (shootRay.wgsl), fills step 0's ray queue.
-//   k_intersect  persistent blocks, one ray per lane, LDS traversal stacks: hitScene (hitRay.wgsl:1-113).
-//                Writes the closest-hit record and sorts each 2048-entry chunk of the ray queue by the
-//                material class of its hit, in place (LDS counting sort, ballot ranks).
-//   k_shade      consumes the sorted queue (bin-uniform waves): ray_color's loop body
-//                (traceRay.wgsl:10-80) + material_scatter + Russian roulette; survivors are compacted
+//   k_prims      hitScene part 1 (hitRay.wgsl:6-54): spheres, quads, root-box test for every queued ray — coherent;
+//                rays that enter the root box go to the step's BVH list.
+//   k_bvh        hitScene part 2 (hitRay.wgsl:42-110): persistent single-wave blocks, one ray per lane, LDS
+//                traversal stacks, ballot-based lane refill from the BVH list; no barriers, tails only at the end.
+//   k_shade      per 2048-path chunk: LDS counting sort by material class (bin-uniform waves), then ray_color's
+//                loop body (traceRay.wgsl:10-80) + material_scatter + Russian roulette; survivors are compacted
 //                in LDS into the next step's ray queue, finished samples fold into the pixel colour.
 //   k_accumulate framebuffer read-modify-write of main.wgsl:22-27 for every frame slot, in frame order.
 #pragma once
@@ -75,67 +76,28 @@ DEV uint32_t bin_rank(int bin, uint32_t* s_cnt) {
   return rank;
 }
 
-// A wave refills its idle lanes from the chunk's BVH list once this many lanes are idle (or all are).
-constexpr int kRefillThreshold = 16;
-
-// Per-block bookkeeping of the chunk being processed lives in a global scratch slab (L2 resident, touched
-// twice per ray) so that LDS is left to the traversal stacks: on a depth-20 tree the stacks alone are 40 KB
-// per 256-thread block and LDS decides how many waves a CU can hold.
-struct ChunkScratch {
-  uint32_t* pid;   // [grid][kChunk] path id of entry j
-  uint16_t* mat;   // [grid][kChunk] effective material of the final hit, 0xffff = miss
-  uint16_t* list;  // [grid][kChunk] entries that traverse the BVH
-  uint16_t* key;   // [grid][kChunk] bin | rank << 3
-};
-
-// hitScene for one chunk of the ray queue, in three phases:
-//   1  every thread takes rays tid, tid+256, ...: spheres, quads and the ROOT box test (hitRay.wgsl:6-54) —
-//      coherent, data in SGPRs.  Rays that do not enter the root box are final; the others are compacted
-//      into a list.
-//   2  persistent lanes: each lane runs the traversal state machine on one listed ray; a wave refills idle
-//      lanes from the list (ballot + one LDS atomic) whenever kRefillThreshold lanes have finished, so
-//      short rays do not leave lanes idle while the longest ray of a wave finishes.
-//      FLAT = false (BVH fits the caches, VALU bound): while-while — inner steps and triangle tests run in
-//      separate loops so each runs with as many lanes as possible.
-//      FLAT = true (large BVH, latency bound): one 64-byte record fetch per lane per iteration.
-//   3  counting sort of the chunk by material class (ballot ranks), written back in place.
-template <bool COUNT, bool FLAT>
-__global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ queue, ChunkScratch G,
-                                                      int stack_size, int stack_alloc, uint32_t target_blocks, unsigned long long* __restrict__ totals) {
-  extern __shared__ int lds_stack[];
-  __shared__ uint32_t s_cnt[NUM_BINS + 2];
-  __shared__ uint32_t s_chunk, s_list_n, s_list_next;
+// hitScene, part 1 (hitRay.wgsl:6-54): spheres, quads and the ROOT box test for every ray of the step's queue.
+// Coherent work (the primitive tables sit in SGPRs); rays that do not enter the root box are final, the others
+// are appended to the step's BVH list (staged in LDS, one global atomic per 2048-ray chunk).
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_prims(DevScene S, Paths P, StepCtl* __restrict__ ctl, const uint32_t* __restrict__ queue,
+                                                  uint32_t* __restrict__ bvh_list, unsigned long long* __restrict__ totals) {
+  __shared__ uint32_t s_list[kChunk];
+  __shared__ uint32_t s_n, s_base;
   const int lane = lane_id();
-  int* stk = lds_stack + (threadIdx.x >> 6) * (stack_alloc * 2 * 64) + lane;
-  uint32_t* g_pid = G.pid + (size_t)blockIdx.x * kChunk;
-  uint16_t* g_mat = G.mat + (size_t)blockIdx.x * kChunk;
-  uint16_t* g_list = G.list + (size_t)blockIdx.x * kChunk;
-  uint16_t* g_key = G.key + (size_t)blockIdx.x * kChunk;
   const uint32_t n = ctl->n_rays;
-  const uint32_t csz = chunk_size_for(n, target_blocks);
   const bool have_bvh = S.n_nodes > 0;
   Counters cn = {0, 0, 0, 0, 0};
-
-  while (true) {
-    if (threadIdx.x == 0) {
-      s_chunk = atomicAdd(&ctl->head_i, 1u);
-      s_list_n = 0;
-      s_list_next = 0;
-    }
-    if (threadIdx.x < NUM_BINS) s_cnt[threadIdx.x] = 0;
+  for (uint32_t base = blockIdx.x * (uint32_t)kChunk; base < n; base += gridDim.x * (uint32_t)kChunk) {
+    const uint32_t m = min((uint32_t)kChunk, n - base);
+    if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    const uint32_t base = s_chunk * csz;
-    if (base >= n) break;
-    const uint32_t m = min(csz, n - base);
-
-    // ---- phase 1 ----
     for (uint32_t j0 = (threadIdx.x & ~63u); j0 < m; j0 += kBlock) {
       const uint32_t j = j0 + lane;
-      const bool active = j < m;
       bool to_bvh = false;
-      if (active) {
-        const uint32_t pid = queue[base + j];
-        g_pid[j] = pid;
+      uint32_t pid = 0;
+      if (j < m) {
+        pid = queue[base + j];
         float4 r0 = P.ray[2 * (size_t)pid], r1 = P.ray[2 * (size_t)pid + 1];
         f3 o = mk3(r0), d = mk3(r1);
         Closest c;
@@ -155,146 +117,150 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, Paths P, StepC
           const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
           to_bvh = hit_aabb(S.root_lo, S.root_hi, c.t, o, inv);
         }
-        const bool hit = (c.prim >> 28) != K_NONE;
         P.hit[pid] = make_float4(c.t, c.u, c.v, __uint_as_float(c.prim));
-        if (hit) P.hitmat[pid] = (uint32_t)c.mat;
-        g_mat[j] = hit ? (uint16_t)c.mat : (uint16_t)0xffffu;
+        P.hitmat[pid] = ((c.prim >> 28) != K_NONE) ? (uint32_t)c.mat : 0xffffffffu;
       }
       const uint64_t lm = __ballot(to_bvh);
       if (lm) {
         const int leader = __ffsll((unsigned long long)lm) - 1;
         uint32_t lb = 0;
-        if (lane == leader) lb = atomicAdd(&s_list_n, (uint32_t)__popcll(lm));
+        if (lane == leader) lb = atomicAdd(&s_n, (uint32_t)__popcll(lm));
         lb = (uint32_t)__shfl((int)lb, leader, 64);
-        if (to_bvh) g_list[lb + lanes_below(lm)] = (uint16_t)j;
-      }
-    }
-    __syncthreads();  // also makes this block's global scratch writes visible to its own waves (same CU)
-
-    // ---- phase 2 ----
-    const uint32_t list_n = s_list_n;
-    if (list_n > 0) {
-      bool has = false;
-      uint32_t myj = 0, mypid = 0;
-      Trav t;
-      t.cur = T_DONE;
-      t.pending = 0;
-      t.sp = 0;
-      t.negmask = 0;
-      t.o = t.d = t.inv = mk3(0, 0, 0);
-      t.orr.mesh = -1;
-      t.orr.o = t.orr.d = mk3(0, 0, 0);
-      t.c.t = 0.0f, t.c.u = t.c.v = 0.0f, t.c.prim = K_NONE, t.c.mat = 0;
-      const uint32_t root = __float_as_uint(S.root_lo.w);
-      for (;;) {
-        // retire finished rays (stores only: nothing here waits on memory)
-        if (has && t.cur == T_DONE && t.pending == 0u) {
-          const bool hit = (t.c.prim >> 28) != K_NONE;
-          P.hit[mypid] = make_float4(t.c.t, t.c.u, t.c.v, __uint_as_float(t.c.prim));
-          if (hit) P.hitmat[mypid] = (uint32_t)t.c.mat;
-          g_mat[myj] = hit ? (uint16_t)t.c.mat : (uint16_t)0xffffu;
-          has = false;
-        }
-        // refill idle lanes
-        uint64_t hm = __ballot(has);
-        int nact = __popcll(hm);
-        bool more = s_list_next < list_n;
-        if (more && (64 - nact) >= (nact == 0 ? 1 : kRefillThreshold)) {
-          const uint64_t idle = ~hm;
-          const int leader = __ffsll((unsigned long long)idle) - 1;
-          uint32_t lb = 0;
-          if (lane == leader) lb = atomicAdd(&s_list_next, (uint32_t)(64 - nact));
-          lb = (uint32_t)__shfl((int)lb, leader, 64);
-          if (!has) {
-            const uint32_t k = lb + lanes_below(idle);
-            if (k < list_n) {
-              myj = g_list[k];
-              mypid = g_pid[myj];
-              float4 r0 = P.ray[2 * (size_t)mypid], r1 = P.ray[2 * (size_t)mypid + 1];
-              float4 h = P.hit[mypid];
-              const uint16_t m16 = g_mat[myj];
-              t.o = mk3(r0);
-              t.d = mk3(r1);
-              t.inv = mk3(1.0f / t.d.x, 1.0f / t.d.y, 1.0f / t.d.z);
-              t.negmask = (t.d.x < 0 ? 1u : 0u) | (t.d.y < 0 ? 2u : 0u) | (t.d.z < 0 ? 4u : 0u);
-              t.c.t = h.x, t.c.u = h.y, t.c.v = h.z, t.c.prim = __float_as_uint(h.w);
-              t.c.mat = (m16 != 0xffffu) ? (int)m16 : 0;
-              t.orr.mesh = -1;
-              t.sp = 0;
-              if (root & REF_LEAF) {
-                t.pending = root;
-                t.cur = T_POP;
-              } else {
-                t.pending = 0;
-                t.cur = root & REF_IDX;
-              }
-              has = true;
-            }
-          }
-          hm = __ballot(has);
-          nact = __popcll(hm);
-          more = s_list_next < list_n;
-        }
-        if (nact == 0) break;
-        // traversal burst: until enough lanes have finished to make a refill worthwhile
-        const int min_working = more ? (64 - kRefillThreshold + 1) : 1;
-        int working;
-        if (FLAT) {
-          do {
-            if (has && !(t.cur == T_DONE && t.pending == 0u)) trav_flat_iter<COUNT>(S, stack_size, stk, t, cn);
-            working = __popcll(__ballot(has && !(t.cur == T_DONE && t.pending == 0u)));
-          } while (working >= min_working);
-        } else {
-          do {
-            while (has && t.cur != T_DONE && t.pending == 0u) trav_step<COUNT>(S, stack_size, stk, t, cn);
-            if (has && t.pending != 0u) {
-              visit_leaf<COUNT>(S, t.pending, t.o, t.d, t.orr, t.c, cn);
-              t.pending = 0u;
-            }
-            working = __popcll(__ballot(has && t.cur != T_DONE));
-          } while (working >= min_working);
-        }
+        if (to_bvh) s_list[lb + lanes_below(lm)] = pid;
       }
     }
     __syncthreads();
-
-    // ---- phase 3: counting sort by material class, scattered back IN PLACE -> bin-uniform shade waves
-    for (uint32_t j0 = (threadIdx.x & ~63u); j0 < m; j0 += kBlock) {
-      const uint32_t j = j0 + lane;
-      int bin = -1;
-      if (j < m) {
-        const uint16_t m16 = g_mat[j];
-        if (m16 == 0xffffu) {
-          bin = BIN_MISS;
-        } else {
-          const float ty = S.mats[4 * (int)m16 + 3].z;
-          bin = (ty == 0.0f) ? BIN_LAMBERTIAN : (ty == 1.0f) ? BIN_MIRROR : (ty == 2.0f) ? BIN_GLASS : (ty == 3.0f) ? BIN_ISOTROPIC : BIN_OTHER;
-        }
-      }
-      const uint32_t rank = bin_rank(bin, s_cnt);
-      if (j < m) g_key[j] = (uint16_t)((uint32_t)bin | (rank << 3));
-    }
+    const uint32_t cnt = s_n;
+    if (threadIdx.x == 0 && cnt) s_base = atomicAdd(&ctl->n_bvh, cnt);
     __syncthreads();
-    uint32_t off[NUM_BINS];
-    uint32_t run = 0;
-#pragma unroll
-    for (int b = 0; b < NUM_BINS; b++) {
-      off[b] = run;
-      run += s_cnt[b];
-    }
-    for (uint32_t j = threadIdx.x; j < m; j += kBlock) {
-      const uint32_t key = g_key[j];
-      const uint32_t b = key & 7u;
-      uint32_t o = off[0];
-#pragma unroll
-      for (int k = 1; k < NUM_BINS; k++) o = (b == (uint32_t)k) ? off[k] : o;
-      queue[base + o + (key >> 3)] = g_pid[j];
-    }
+    const uint32_t ob = s_base;
+    for (uint32_t j = threadIdx.x; j < cnt; j += kBlock) bvh_list[ob + j] = s_list[j];
     __syncthreads();
   }
-
   if (COUNT) {
-    // wave reduction, then one atomic per counter per wave
+    uint32_t v[5] = {cn.node_visits, cn.tri_tests, cn.sphere_tests, cn.quad_tests, cn.mat_fetches};
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      unsigned long long x = v[k];
+      for (int off2 = 32; off2 > 0; off2 >>= 1) x += __shfl_down(x, off2, 64);
+      if (lane == 0 && x) atomicAdd(&totals[2 + k], x);
+    }
+  }
+}
+
+// A wave refills its idle lanes from its range of the BVH list once this many lanes are idle (or all are).
+constexpr int kRefillThreshold = 16;
+constexpr uint32_t kBvhRange = 512;  // list entries a wave claims per global atomic (less when the list is short)
+
+// hitScene, part 2 (hitRay.wgsl:42-110): BVH traversal of the listed rays by persistent, barrier-free waves.
+// One block = one wave, so LDS (the traversal stacks, stack_alloc x 512 B per wave) is the only thing that limits
+// how many waves a CU holds.  Each lane runs the traversal state machine on one ray; when kRefillThreshold lanes
+// have finished, the wave refills them (ballot) from the range of the list it has claimed (one global atomic per
+// kBvhRange rays), so short rays never leave lanes idle behind a long one and tails exist only at kernel end.
+//   FLAT = false (BVH fits the caches, VALU bound): while-while — inner steps and triangle tests run in
+//   separate loops so that each runs with as many lanes as possible.
+//   FLAT = true (large BVH, latency bound): one 64-byte record fetch per lane per iteration.
+template <bool COUNT, bool FLAT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_bvh(DevScene S, Paths P, StepCtl* __restrict__ ctl,
+                                                                                       const uint32_t* __restrict__ bvh_list, int stack_size,
+                                                                                       int refill_threshold, unsigned long long* __restrict__ totals) {
+  extern __shared__ int lds_stack[];
+  const int lane = lane_id();
+  int* stk = lds_stack + lane;
+  const uint32_t n = ctl->n_bvh;
+  // short lists (the Russian-roulette tail) are cut into smaller ranges so that they still spread over all waves
+  const uint32_t range = min(kBvhRange, max(64u, ((n / (2u * gridDim.x)) + 63u) & ~63u));
+  Counters cn = {0, 0, 0, 0, 0};
+  uint32_t rb = 0, re = 0;  // this wave's claimed range of the list (wave-uniform)
+  bool exhausted = (n == 0);
+  bool has = false;
+  uint32_t mypid = 0;
+  Trav t;
+  t.cur = T_DONE;
+  t.pending = 0;
+  t.sp = 0;
+  t.negmask = 0;
+  t.o = t.d = t.inv = mk3(0, 0, 0);
+  t.orr.mesh = -1;
+  t.orr.o = t.orr.d = mk3(0, 0, 0);
+  t.c.t = 0.0f, t.c.u = t.c.v = 0.0f, t.c.prim = K_NONE, t.c.mat = 0;
+  const uint32_t root = __float_as_uint(S.root_lo.w);
+  for (;;) {
+    // retire finished rays (stores only: nothing here waits on memory)
+    if (has && t.cur == T_DONE && t.pending == 0u) {
+      P.hit[mypid] = make_float4(t.c.t, t.c.u, t.c.v, __uint_as_float(t.c.prim));
+      P.hitmat[mypid] = ((t.c.prim >> 28) != K_NONE) ? (uint32_t)t.c.mat : 0xffffffffu;
+      has = false;
+    }
+    uint64_t hm = __ballot(has);
+    int nact = __popcll(hm);
+    if ((64 - nact) >= (nact == 0 ? 1 : refill_threshold)) {
+      if (rb == re && !exhausted) {  // claim the next range
+        uint32_t nb = 0;
+        if (lane == 0) nb = atomicAdd(&ctl->head_b, range);
+        nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+        if (nb >= n) {
+          exhausted = true;
+        } else {
+          rb = nb;
+          re = min(nb + range, n);
+        }
+      }
+      const uint32_t avail = re - rb;
+      if (avail) {
+        const uint64_t idle = ~hm;
+        const uint32_t k = lanes_below(idle);
+        if (!has && k < avail) {
+          mypid = bvh_list[rb + k];
+          float4 r0 = P.ray[2 * (size_t)mypid], r1 = P.ray[2 * (size_t)mypid + 1];
+          float4 h = P.hit[mypid];
+          const uint32_t hmat = P.hitmat[mypid];
+          t.o = mk3(r0);
+          t.d = mk3(r1);
+          t.inv = mk3(1.0f / t.d.x, 1.0f / t.d.y, 1.0f / t.d.z);
+          t.negmask = (t.d.x < 0 ? 1u : 0u) | (t.d.y < 0 ? 2u : 0u) | (t.d.z < 0 ? 4u : 0u);
+          t.c.t = h.x, t.c.u = h.y, t.c.v = h.z, t.c.prim = __float_as_uint(h.w);
+          t.c.mat = (hmat != 0xffffffffu) ? (int)hmat : 0;
+          t.orr.mesh = -1;
+          t.sp = 0;
+          if (root & REF_LEAF) {
+            t.pending = root;
+            t.cur = T_POP;
+          } else {
+            t.pending = 0;
+            t.cur = root & REF_IDX;
+          }
+          has = true;
+        }
+        rb += min(avail, (uint32_t)(64 - nact));
+        hm = __ballot(has);
+        nact = __popcll(hm);
+      }
+    }
+    if (nact == 0) {
+      if (exhausted) break;
+      continue;  // range was empty: claim the next one
+    }
+    const bool more = !(exhausted && rb == re);
+    const int min_working = more ? (64 - refill_threshold + 1) : 1;
+    int working;
+    if (FLAT) {
+      do {
+        if (has && !(t.cur == T_DONE && t.pending == 0u)) trav_flat_iter<COUNT>(S, stack_size, stk, t, cn);
+        working = __popcll(__ballot(has && !(t.cur == T_DONE && t.pending == 0u)));
+      } while (working >= min_working);
+    } else {
+      do {
+        while (has && t.cur != T_DONE && t.pending == 0u) trav_step<COUNT>(S, stack_size, stk, t, cn);
+        if (has && t.pending != 0u) {
+          visit_leaf<COUNT>(S, t.pending, t.o, t.d, t.orr, t.c, cn);
+          t.pending = 0u;
+        }
+        working = __popcll(__ballot(has && t.cur != T_DONE));
+      } while (working >= min_working);
+    }
+  }
+  if (COUNT) {
     uint32_t v[5] = {cn.node_visits, cn.tri_tests, cn.sphere_tests, cn.quad_tests, cn.mat_fetches};
 #pragma unroll
     for (int k = 0; k < 5; k++) {
@@ -432,7 +398,9 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, uin
 template <bool IS>
 __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, const uint32_t* __restrict__ queue,
                                                   uint32_t* __restrict__ q_next, uint32_t target_blocks) {
-  __shared__ uint32_t s_out[kChunk];
+  __shared__ uint32_t s_out[kChunk];     // survivors of the chunk
+  __shared__ uint32_t s_sorted[kChunk];  // the chunk's path ids grouped by material class
+  __shared__ uint32_t s_cnt[NUM_BINS + 2];
   __shared__ uint32_t s_chunk, s_next, s_nout, s_base;
   const QuadL L = load_light(S);
   const int lane = lane_id();
@@ -444,10 +412,58 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst rc, Pa
       s_next = 0;
       s_nout = 0;
     }
+    if (threadIdx.x < NUM_BINS) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t base = s_chunk * csz;
     if (base >= n) break;
     const uint32_t m = min(csz, n - base);
+    // prologue: counting sort of the chunk by the material class of each path's hit (ballot ranks + LDS
+    // counters), so that the waves below are (almost) uniform in the 4-way material switch of scatterRay.wgsl
+    uint32_t keys[kChunk / kBlock];
+    uint32_t pids[kChunk / kBlock];
+#pragma unroll
+    for (int r = 0; r < kChunk / kBlock; r++) {
+      const uint32_t j = (uint32_t)r * kBlock + threadIdx.x;
+      int bin = -1;
+      pids[r] = 0;
+      if (j < m) {
+        const uint32_t pid = queue[base + j];
+        pids[r] = pid;
+        const uint32_t hmat = P.hitmat[pid];
+        if (hmat == 0xffffffffu) {
+          bin = BIN_MISS;
+        } else {
+          const float ty = S.mats[4 * (int)hmat + 3].z;
+          bin = (ty == 0.0f) ? BIN_LAMBERTIAN : (ty == 1.0f) ? BIN_MIRROR : (ty == 2.0f) ? BIN_GLASS : (ty == 3.0f) ? BIN_ISOTROPIC : BIN_OTHER;
+        }
+      }
+      const bool any = (uint32_t)r * kBlock < m;  // block-uniform: skip empty rounds of small chunks
+      uint32_t rank = 0;
+      if (any) rank = bin_rank(bin, s_cnt);
+      keys[r] = (uint32_t)(bin & 7) | (rank << 3);
+    }
+    __syncthreads();
+    {
+      uint32_t off[NUM_BINS];
+      uint32_t run = 0;
+#pragma unroll
+      for (int b = 0; b < NUM_BINS; b++) {
+        off[b] = run;
+        run += s_cnt[b];
+      }
+#pragma unroll
+      for (int r = 0; r < kChunk / kBlock; r++) {
+        const uint32_t j = (uint32_t)r * kBlock + threadIdx.x;
+        if (j < m) {
+          const uint32_t b = keys[r] & 7u;
+          uint32_t o = off[0];
+#pragma unroll
+          for (int k = 1; k < NUM_BINS; k++) o = (b == (uint32_t)k) ? off[k] : o;
+          s_sorted[o + (keys[r] >> 3)] = pids[r];
+        }
+      }
+    }
+    __syncthreads();
     while (true) {
       uint32_t sub = 0;
       if (lane == 0) sub = atomicAdd(&s_next, 64u);
@@ -457,7 +473,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst rc, Pa
       bool survive = false;
       uint32_t pid = 0;
       if (j < m) {
-        pid = queue[base + j];
+        pid = s_sorted[j];
         survive = shade_one<IS>(S, rc, P, pid, L);
       }
       const uint64_t mk = __ballot(survive);
