@@ -691,7 +691,9 @@ int ptmi_render(ptmi_ctx* c, const float* view16, uint32_t first_frame, uint32_t
   r = check_renderable(c);
   if (r) return r;
   size_t npix = (size_t)c->W * c->H;
-  uint32_t F = c->prm.frames_in_flight > 0 ? (uint32_t)c->prm.frames_in_flight : 16u;
+  // auto: as many frames per wavefront pass as a 128 M-path budget allows (64 at 1080p, 16 at 4K; ~100 B of state per
+  // path): the sparse Russian-roulette tail steps and every launch are amortised over more rays
+  uint32_t F = c->prm.frames_in_flight > 0 ? (uint32_t)c->prm.frames_in_flight : (uint32_t)std::max<size_t>(1, std::min<size_t>(64, ((size_t)1 << 27) / npix));
   size_t max_f = std::max<size_t>(1, (size_t)0x0fffffff / npix);  // path ids stay below 2^28
   F = (uint32_t)std::min<size_t>(F, max_f);
   for (uint32_t done = 0; done < n_frames;) {
