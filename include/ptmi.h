@@ -74,12 +74,16 @@ typedef struct ptmi_stats {
   uint64_t quad_tests;   /* hit_quad calls                                                    */
   uint64_t mat_fetches;  /* `hitRec.material = materials[..]` executions                      */
   uint64_t frames;       /* frames rendered                                                   */
-  uint64_t intersect_launches;
+  uint64_t intersect_launches; /* steps: each launches k_prims and (if there are triangles) k_bvh */
   uint64_t shade_launches;
+  uint64_t bvh_node_visits;    /* the part of node_visits made by k_bvh (everything below the root) */
+  uint64_t bvh_mat_fetches;    /* the part of mat_fetches made by k_bvh (accepted triangle hits)    */
   double render_ms;      /* generate..accumulate, all batches                                 */
-  double intersect_ms;   /* sum over intersect launches                                       */
-  double shade_ms;       /* sum over shade launches                                           */
-  double other_ms;       /* generate + accumulate                                             */
+  double intersect_ms;   /* prims_ms + bvh_ms                                                 */
+  double shade_ms;       /* sum over k_shade launches                                         */
+  double other_ms;       /* k_generate + k_accumulate                                         */
+  double prims_ms;       /* sum over k_prims launches (spheres, quads, root box)              */
+  double bvh_ms;         /* sum over k_bvh launches (traversal)                               */
 } ptmi_stats;
 
 /* One hitScene result, the fields of the reference's HitRecord (shaders/header.wgsl:119-125). */

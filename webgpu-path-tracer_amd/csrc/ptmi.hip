@@ -43,7 +43,7 @@ struct DBuf {
   }
 };
 
-enum TimerTag { T_INTERSECT = 0, T_SHADE = 1, T_OTHER = 2, T_RENDER = 3, T_NTAGS = 4 };
+enum TimerTag { T_PRIMS = 0, T_SHADE = 1, T_OTHER = 2, T_RENDER = 3, T_BVH = 4 };
 
 }  // namespace
 
@@ -132,7 +132,8 @@ void drain_spans(ptmi_ctx* c) {  // call after the stream is idle
   for (auto& s : c->spans) {
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
-      if (s.tag == T_INTERSECT) c->stats.intersect_ms += ms;
+      if (s.tag == T_PRIMS) c->stats.prims_ms += ms, c->stats.intersect_ms += ms;
+      else if (s.tag == T_BVH) c->stats.bvh_ms += ms, c->stats.intersect_ms += ms;
       else if (s.tag == T_SHADE) c->stats.shade_ms += ms;
       else if (s.tag == T_OTHER) c->stats.other_ms += ms;
       else c->stats.render_ms += ms;
@@ -376,8 +377,8 @@ int ensure_paths(ptmi_ctx* c, size_t npaths, int n_ctl, bool need_pixsum) {
     c->ctl_cap = n_ctl;
   }
   if (!c->d_totals.p) {
-    HIP_TRY(c, c->d_totals.ensure(8 * sizeof(unsigned long long)));
-    HIP_TRY(c, hipMemsetAsync(c->d_totals.p, 0, 8 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, c->d_totals.ensure(16 * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMemsetAsync(c->d_totals.p, 0, 16 * sizeof(unsigned long long), c->stream));
   }
   return PTMI_OK;
 }
@@ -416,9 +417,13 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, const uint32_t* 
   unsigned long long* tot = c->d_totals.as<unsigned long long>();
   uint32_t* list = c->d_bvhlist.as<uint32_t>();
   const uint32_t pgrid = std::max<uint32_t>(1, std::min<uint32_t>((max_items + kChunk - 1) / kChunk, (uint32_t)c->num_cus * 8));
-  if (c->counters) hipLaunchKernelGGL(k_prims<true>, dim3(pgrid), dim3(kBlock), 0, c->stream, c->S, P, ctl, queue, list, tot);
-  else hipLaunchKernelGGL(k_prims<false>, dim3(pgrid), dim3(kBlock), 0, c->stream, c->S, P, ctl, queue, list, tot);
+  {
+    ScopedSpan sp(c, T_PRIMS);
+    if (c->counters) hipLaunchKernelGGL(k_prims<true>, dim3(pgrid), dim3(kBlock), 0, c->stream, c->S, P, ctl, queue, list, tot);
+    else hipLaunchKernelGGL(k_prims<false>, dim3(pgrid), dim3(kBlock), 0, c->stream, c->S, P, ctl, queue, list, tot);
+  }
   if (c->S.n_nodes <= 0) return PTMI_OK;
+  ScopedSpan sp(c, T_BVH);
   const int sa = stack_alloc_for(c);
   const size_t lds = (size_t)sa * 2 * 64 * sizeof(int);  // one wave per block, two words per stack entry
   const bool flat = use_flat(c);
@@ -491,7 +496,6 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   }
   for (int s = 0; s < n_steps; s++) {
     {
-      ScopedSpan sp(c, T_INTERSECT);
       int lr = launch_intersect(c, P, ctl + s, q[s & 1], total);
       if (lr) return lr;
     }
@@ -792,10 +796,11 @@ int ptmi_get_stats(ptmi_ctx* c, ptmi_stats* out) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_spans(c);
   if (c->d_totals.p) {
-    unsigned long long t[8];
+    unsigned long long t[16];
     HIP_TRY(c, hipMemcpy(t, c->d_totals.p, sizeof t, hipMemcpyDeviceToHost));
     c->stats.rays = t[0], c->stats.paths = t[1], c->stats.node_visits = t[2], c->stats.tri_tests = t[3];
     c->stats.sphere_tests = t[4], c->stats.quad_tests = t[5], c->stats.mat_fetches = t[6];
+    c->stats.bvh_node_visits = t[7], c->stats.bvh_mat_fetches = t[8];
   }
   *out = c->stats;
   return PTMI_OK;
@@ -807,7 +812,7 @@ int ptmi_reset_stats(ptmi_ctx* c) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_spans(c);
   memset(&c->stats, 0, sizeof c->stats);
-  if (c->d_totals.p) HIP_TRY(c, hipMemset(c->d_totals.p, 0, 8 * sizeof(unsigned long long)));
+  if (c->d_totals.p) HIP_TRY(c, hipMemset(c->d_totals.p, 0, 16 * sizeof(unsigned long long)));
   return PTMI_OK;
 }
 

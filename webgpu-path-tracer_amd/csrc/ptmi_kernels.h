@@ -266,7 +266,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     for (int k = 0; k < 5; k++) {
       unsigned long long x = v[k];
       for (int off2 = 32; off2 > 0; off2 >>= 1) x += __shfl_down(x, off2, 64);
-      if (lane == 0 && x) atomicAdd(&totals[2 + k], x);
+      if (lane == 0 && x) {
+        atomicAdd(&totals[2 + k], x);
+        if (k == 0) atomicAdd(&totals[7], x);  // node visits below the root
+        if (k == 4) atomicAdd(&totals[8], x);  // accepted triangle hits
+      }
     }
   }
 }

@@ -438,6 +438,10 @@ static napi_value js_stats(napi_env env, napi_callback_info info) {
   set_f64(env, o, "intersect_ms", s.intersect_ms);
   set_f64(env, o, "shade_ms", s.shade_ms);
   set_f64(env, o, "other_ms", s.other_ms);
+  set_f64(env, o, "prims_ms", s.prims_ms);
+  set_f64(env, o, "bvh_ms", s.bvh_ms);
+  set_f64(env, o, "bvh_node_visits", (double)s.bvh_node_visits);
+  set_f64(env, o, "bvh_mat_fetches", (double)s.bvh_mat_fetches);
   return o;
 }
 

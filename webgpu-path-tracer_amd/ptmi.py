@@ -32,7 +32,8 @@ class Params(ctypes.Structure):
 class Stats(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint64) for n in (
         "rays", "paths", "node_visits", "tri_tests", "sphere_tests", "quad_tests", "mat_fetches", "frames",
-        "intersect_launches", "shade_launches")] + [(n, ctypes.c_double) for n in ("render_ms", "intersect_ms", "shade_ms", "other_ms")]
+        "intersect_launches", "shade_launches", "bvh_node_visits", "bvh_mat_fetches")] + [
+        (n, ctypes.c_double) for n in ("render_ms", "intersect_ms", "shade_ms", "other_ms", "prims_ms", "bvh_ms")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
