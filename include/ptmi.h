@@ -152,6 +152,8 @@ int ptmi_stream(ptmi_ctx* ctx, void** stream);
 int ptmi_resolve_rgba8(ptmi_ctx* ctx, float frame_num, uint8_t* dst, size_t bytes);
 
 int ptmi_set_counters(ptmi_ctx* ctx, int enabled);
+/* 0 = off; 1 = HIP events around every kernel launch; 2 = only around k_bvh (the dominant kernel): fewer stream
+ * markers, for timing a region whose wall clock also matters. */
 int ptmi_set_timing(ptmi_ctx* ctx, int enabled);
 int ptmi_get_stats(ptmi_ctx* ctx, ptmi_stats* out); /* synchronises */
 int ptmi_reset_stats(ptmi_ctx* ctx);

@@ -72,11 +72,14 @@ struct ptmi_ctx {
 
   size_t path_cap = 0;
   bool pixsum_alloc = false;
-  DBuf d_ray, d_thr, d_acc, d_pixsum, d_rng, d_hit, d_hitmat, d_q0, d_q1, d_ctl, d_totals, d_scratch, d_bvhlist;
+  size_t slot_cap = 0;  // slots per queue buffer (paths + room for the holes k_shade's regions leave)
+  DBuf d_so[2], d_sd[2], d_sthr[2], d_srng[2], d_spid[2];  // slot-indexed live state, ping-pong
+  DBuf d_acc, d_pixsum, d_hit, d_hitmat, d_ctl, d_totals, d_scratch;
   int traversal_mode = 0;  // 0 auto, 1 while-while, 2 flat
   int ctl_cap = 0;
 
-  bool counters = false, timing = false;
+  bool counters = false;
+  int timing = 0;  // 0 off, 1 every kernel, 2 only k_bvh (the dominant kernel) — see ptmi_set_timing
   ptmi_stats stats{};
   std::vector<hipEvent_t> ev_pool;
   struct Span {
@@ -115,7 +118,7 @@ struct ScopedSpan {  // records a begin/end event pair around launches when timi
   ptmi_ctx* c;
   ptmi_ctx::Span s{};
   bool on;
-  ScopedSpan(ptmi_ctx* c_, int tag) : c(c_), on(c_->timing) {
+  ScopedSpan(ptmi_ctx* c_, int tag) : c(c_), on(c_->timing == 1 || (c_->timing == 2 && tag == T_BVH)) {
     if (!on) return;
     s.tag = tag;
     s.a = get_event(c);
@@ -356,16 +359,21 @@ uint32_t count_local(uint32_t npix, int rank, int world, int tile) {
 
 int ensure_paths(ptmi_ctx* c, size_t npaths, int n_ctl, bool need_pixsum) {
   if (npaths > c->path_cap) {
-    HIP_TRY(c, c->d_ray.ensure(npaths * 32));
-    HIP_TRY(c, c->d_thr.ensure(npaths * 16));
+    // A queue holds at most `npaths` paths plus the holes of k_shade's output regions: at most one region per block
+    // (region <= slots/grid/16 rounded up to 512) — 1/8 of the paths plus 1024 slots per possible block is ample.
+    const size_t slots = npaths + npaths / 8 + (size_t)c->num_cus * 8 * 1024;
+    for (int k = 0; k < 2; k++) {
+      HIP_TRY(c, c->d_so[k].ensure(slots * 16));
+      HIP_TRY(c, c->d_sd[k].ensure(slots * 16));
+      HIP_TRY(c, c->d_sthr[k].ensure(slots * 16));
+      HIP_TRY(c, c->d_srng[k].ensure(slots * 4));
+      HIP_TRY(c, c->d_spid[k].ensure(slots * 4));
+    }
+    HIP_TRY(c, c->d_hit.ensure(slots * 16));
+    HIP_TRY(c, c->d_hitmat.ensure(slots * 4));
     HIP_TRY(c, c->d_acc.ensure(npaths * 16));
-    HIP_TRY(c, c->d_rng.ensure(npaths * 4));
-    HIP_TRY(c, c->d_hit.ensure(npaths * 16));
-    HIP_TRY(c, c->d_hitmat.ensure(npaths * 4));
-    HIP_TRY(c, c->d_q0.ensure(npaths * 4));
-    HIP_TRY(c, c->d_q1.ensure(npaths * 4));
-    HIP_TRY(c, c->d_bvhlist.ensure(npaths * 4));
     c->path_cap = npaths;
+    c->slot_cap = slots;
     c->pixsum_alloc = false;
   }
   if (need_pixsum && !c->pixsum_alloc) {
@@ -383,15 +391,17 @@ int ensure_paths(ptmi_ctx* c, size_t npaths, int n_ctl, bool need_pixsum) {
   return PTMI_OK;
 }
 
-Paths paths_of(ptmi_ctx* c, bool with_pixsum) {
+// Path state as step `step` sees it: `in` = buffers (step & 1), `out` = the other pair.
+Paths paths_of(ptmi_ctx* c, int step, bool with_pixsum) {
   Paths P;
-  P.ray = c->d_ray.as<float4>();
-  P.thr = c->d_thr.as<float4>();
-  P.acc = c->d_acc.as<float4>();
-  P.pixsum = with_pixsum ? c->d_pixsum.as<float4>() : nullptr;
-  P.rng = c->d_rng.as<uint32_t>();
+  const int a = step & 1, b = a ^ 1;
+  P.in = Slots{c->d_so[a].as<float4>(), c->d_sd[a].as<float4>(), c->d_sthr[a].as<float4>(), c->d_srng[a].as<uint32_t>(), c->d_spid[a].as<uint32_t>()};
+  P.out = Slots{c->d_so[b].as<float4>(), c->d_sd[b].as<float4>(), c->d_sthr[b].as<float4>(), c->d_srng[b].as<uint32_t>(), c->d_spid[b].as<uint32_t>()};
   P.hit = c->d_hit.as<float4>();
   P.hitmat = c->d_hitmat.as<uint32_t>();
+  P.acc = c->d_acc.as<float4>();
+  P.pixsum = with_pixsum ? c->d_pixsum.as<float4>() : nullptr;
+  P.cap = (uint32_t)c->slot_cap;
   return P;
 }
 
@@ -412,20 +422,19 @@ int env_int(const char* name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 
-// hitScene for the step's queue: k_prims (coherent part + BVH list) then k_bvh (traversal).
-int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, const uint32_t* queue, uint32_t max_items) {
+// hitScene for the step's queue: k_prims (element-wise part, flags the rays that enter the root box) then k_bvh.
+int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_items) {
   unsigned long long* tot = c->d_totals.as<unsigned long long>();
-  uint32_t* list = c->d_bvhlist.as<uint32_t>();
-  const uint32_t pgrid = std::max<uint32_t>(1, std::min<uint32_t>((max_items + kChunk - 1) / kChunk, (uint32_t)c->num_cus * 8));
+  const uint32_t pgrid = std::max<uint32_t>(1, std::min<uint32_t>((max_items + kBlock - 1) / kBlock, (uint32_t)c->num_cus * 32));
   {
     ScopedSpan sp(c, T_PRIMS);
-    if (c->counters) hipLaunchKernelGGL(k_prims<true>, dim3(pgrid), dim3(kBlock), 0, c->stream, c->S, P, ctl, queue, list, tot);
-    else hipLaunchKernelGGL(k_prims<false>, dim3(pgrid), dim3(kBlock), 0, c->stream, c->S, P, ctl, queue, list, tot);
+    if (c->counters) hipLaunchKernelGGL(k_prims<true>, dim3(pgrid), dim3(kBlock), 0, c->stream, c->S, P, ctl, tot);
+    else hipLaunchKernelGGL(k_prims<false>, dim3(pgrid), dim3(kBlock), 0, c->stream, c->S, P, ctl, tot);
   }
   if (c->S.n_nodes <= 0) return PTMI_OK;
   ScopedSpan sp(c, T_BVH);
   const int sa = stack_alloc_for(c);
-  const size_t lds = (size_t)sa * 2 * 64 * sizeof(int);  // one wave per block, two words per stack entry
+  const size_t lds = (size_t)sa * 2 * 64 * sizeof(int) + 128 * sizeof(uint32_t);  // stacks (2 words/entry) + candidate buffer
   const bool flat = use_flat(c);
   // VGPR budget: flat variant <= 128 VGPRs (4 waves/SIMD), while-while <= 96 (5 waves/SIMD)
   int waves_per_cu = (int)std::min<size_t>(flat ? 16 : 20, (size_t)(160 * 1024) / (lds + 64));
@@ -433,7 +442,7 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, const uint32_t* 
   const uint32_t want = (max_items + 63) / 64;
   const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(want, (uint32_t)c->num_cus * (uint32_t)waves_per_cu));
   const int thr = env_int("PTMI_REFILL", kRefillThreshold);
-#define PTMI_LAUNCH_BVH(CNT, FL) hipLaunchKernelGGL((k_bvh<CNT, FL>), dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, list, c->prm.stack_size, thr, tot)
+#define PTMI_LAUNCH_BVH(CNT, FL) hipLaunchKernelGGL((k_bvh<CNT, FL>), dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->prm.stack_size, sa, thr, tot)
   if (c->counters) {
     if (flat) PTMI_LAUNCH_BVH(true, true);
     else PTMI_LAUNCH_BVH(true, false);
@@ -479,40 +488,39 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   if (rc.n_local == 0) return PTMI_OK;
 
   const int n_steps = rc.num_samples * p.max_bounces;
-  const size_t npaths = (size_t)rc.npix * (size_t)n_frames;
+  const size_t npaths = (size_t)rc.n_local * (size_t)n_frames;
   int rcode = ensure_paths(c, npaths, n_steps + 2, rc.num_samples > 1);
   if (rcode) return rcode;
-  Paths P = paths_of(c, rc.num_samples > 1);
   StepCtl* ctl = c->d_ctl.as<StepCtl>();
   const uint32_t total = rc.n_local * (uint32_t)n_frames;
-  uint32_t* q[2] = {c->d_q0.as<uint32_t>(), c->d_q1.as<uint32_t>()};
+  const uint32_t bound = total + total / 8 + (uint32_t)c->num_cus * 8 * 1024;  // slots a step's queue can span
   const uint32_t ew_grid = std::max<uint32_t>(1, std::min<uint32_t>((total + kBlock - 1) / kBlock, (uint32_t)c->num_cus * 16));
+  const uint32_t sgrid = std::max<uint32_t>(1, std::min<uint32_t>((bound + kSChunk - 1) / kSChunk, (uint32_t)c->num_cus * 5));
+  unsigned long long* tot = c->d_totals.as<unsigned long long>();
 
   ScopedSpan whole(c, T_RENDER);
   {
     ScopedSpan s(c, T_OTHER);
     HIP_TRY(c, hipMemsetAsync(ctl, 0, (size_t)(n_steps + 2) * sizeof(StepCtl), c->stream));
-    hipLaunchKernelGGL(k_generate, dim3(ew_grid), dim3(kBlock), 0, c->stream, rc, P, q[0], ctl);
+    hipLaunchKernelGGL(k_generate, dim3(ew_grid), dim3(kBlock), 0, c->stream, rc, paths_of(c, 0, rc.num_samples > 1), ctl);
   }
   for (int s = 0; s < n_steps; s++) {
+    Paths P = paths_of(c, s, rc.num_samples > 1);
     {
-      int lr = launch_intersect(c, P, ctl + s, q[s & 1], total);
+      int lr = launch_intersect(c, P, ctl + s, bound);
       if (lr) return lr;
     }
     {
       ScopedSpan sp(c, T_SHADE);
-      const uint32_t sgrid = chunk_grid(c, total, 8);
-      if (p.importance_sampling)
-        hipLaunchKernelGGL(k_shade<true>, dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, q[s & 1], q[(s + 1) & 1], sgrid);
-      else
-        hipLaunchKernelGGL(k_shade<false>, dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, q[s & 1], q[(s + 1) & 1], sgrid);
+      if (p.importance_sampling) hipLaunchKernelGGL(k_shade<true>, dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, tot);
+      else hipLaunchKernelGGL(k_shade<false>, dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, tot);
     }
     c->stats.intersect_launches++;
     c->stats.shade_launches++;
   }
   {
     ScopedSpan s(c, T_OTHER);
-    hipLaunchKernelGGL(k_accumulate, dim3(ew_grid), dim3(kBlock), 0, c->stream, rc, P, c->fb, ctl, n_steps, c->d_totals.as<unsigned long long>());
+    hipLaunchKernelGGL(k_accumulate, dim3(ew_grid), dim3(kBlock), 0, c->stream, rc, paths_of(c, 0, false), c->fb, ctl, n_steps, tot);
   }
   HIP_TRY(c, hipGetLastError());
   c->stats.frames += (uint64_t)n_frames;
@@ -602,8 +610,9 @@ void ptmi_destroy(ptmi_ctx* c) {
   drain_spans(c);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (DBuf* b : {&c->d_spheres, &c->d_sphere_info, &c->d_quads, &c->d_quad_mat, &c->d_tris, &c->d_pretri, &c->d_meshes, &c->d_xforms,
-                  &c->d_mats, &c->d_pairs, &c->d_leaf_table, &c->d_fb_own, &c->d_ray, &c->d_thr, &c->d_acc, &c->d_pixsum, &c->d_rng, &c->d_hit, &c->d_hitmat,
-                  &c->d_q0, &c->d_q1, &c->d_bvhlist, &c->d_ctl, &c->d_totals, &c->d_scratch})
+                  &c->d_mats, &c->d_pairs, &c->d_leaf_table, &c->d_fb_own, &c->d_so[0], &c->d_so[1], &c->d_sd[0], &c->d_sd[1], &c->d_sthr[0],
+                  &c->d_sthr[1], &c->d_srng[0], &c->d_srng[1], &c->d_spid[0], &c->d_spid[1], &c->d_acc, &c->d_pixsum, &c->d_hit, &c->d_hitmat,
+                  &c->d_ctl, &c->d_totals, &c->d_scratch})
     b->release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -694,10 +703,11 @@ int ptmi_render(ptmi_ctx* c, const float* view16, uint32_t first_frame, uint32_t
   if (r) return r;
   r = check_renderable(c);
   if (r) return r;
-  size_t npix = (size_t)c->W * c->H;
-  // auto: as many frames per wavefront pass as a 128 M-path budget allows (64 at 1080p, 16 at 4K; ~100 B of state per
+  // pixels this context owns; a rank that renders 1/N of the image keeps N times more frames in flight
+  const size_t npix = std::max<size_t>(1, count_local((uint32_t)c->W * (uint32_t)c->H, c->rank, c->world, c->tile));
+  // auto: as many frames per wavefront pass as a 128 M-path budget allows (64 at 1080p, 16 at 4K; ~150 B of state per
   // path): the sparse Russian-roulette tail steps and every launch are amortised over more rays
-  uint32_t F = c->prm.frames_in_flight > 0 ? (uint32_t)c->prm.frames_in_flight : (uint32_t)std::max<size_t>(1, std::min<size_t>(64, ((size_t)1 << 27) / npix));
+  uint32_t F = c->prm.frames_in_flight > 0 ? (uint32_t)c->prm.frames_in_flight : (uint32_t)std::max<size_t>(1, std::min<size_t>(1024, ((size_t)1 << 27) / npix));
   size_t max_f = std::max<size_t>(1, (size_t)0x0fffffff / npix);  // path ids stay below 2^28
   F = (uint32_t)std::min<size_t>(F, max_f);
   for (uint32_t done = 0; done < n_frames;) {
@@ -786,7 +796,7 @@ int ptmi_set_counters(ptmi_ctx* c, int on) {
 }
 int ptmi_set_timing(ptmi_ctx* c, int on) {
   if (!c) return PTMI_ERR_INVALID_ARG;
-  c->timing = on != 0;
+  c->timing = on < 0 ? 0 : (on > 2 ? 1 : on);
   return PTMI_OK;
 }
 
@@ -801,6 +811,7 @@ int ptmi_get_stats(ptmi_ctx* c, ptmi_stats* out) {
     c->stats.rays = t[0], c->stats.paths = t[1], c->stats.node_visits = t[2], c->stats.tri_tests = t[3];
     c->stats.sphere_tests = t[4], c->stats.quad_tests = t[5], c->stats.mat_fetches = t[6];
     c->stats.bvh_node_visits = t[7], c->stats.bvh_mat_fetches = t[8];
+    if (t[15]) return fail(c, PTMI_ERR_STATE, "internal: a step's queue outgrew its buffer (paths were dropped)");
   }
   *out = c->stats;
   return PTMI_OK;
@@ -826,30 +837,30 @@ int ptmi_trace(ptmi_ctx* c, size_t n, const float* rays6, uint32_t* rng_inout, p
   if (r) return r;
   r = ensure_paths(c, n, 4, false);
   if (r) return r;
-  Paths P = paths_of(c, false);
-  // stage: rays as 2 float4 each, identity queue
-  std::vector<float> stage(8 * n);
+  Paths P = paths_of(c, 0, false);
+  // stage: one slot per ray (slot i = path i)
+  std::vector<float> so(4 * n, 0.0f), sd(4 * n, 0.0f);
   std::vector<uint32_t> ident(n), rng(n, 0u);
   for (size_t i = 0; i < n; i++) {
-    for (int k = 0; k < 3; k++) stage[8 * i + k] = rays6[6 * i + k], stage[8 * i + 4 + k] = rays6[6 * i + 3 + k];
-    stage[8 * i + 3] = stage[8 * i + 7] = 0.0f;
+    for (int k = 0; k < 3; k++) so[4 * i + k] = rays6[6 * i + k], sd[4 * i + k] = rays6[6 * i + 3 + k];
     ident[i] = (uint32_t)i;
     if (rng_inout) rng[i] = rng_inout[i];
   }
   StepCtl ctl0{};
   ctl0.n_rays = (uint32_t)n;
   StepCtl* ctl = c->d_ctl.as<StepCtl>();
-  HIP_TRY(c, hipMemcpyAsync(P.ray, stage.data(), stage.size() * 4, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(P.rng, rng.data(), n * 4, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->d_q0.p, ident.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(P.in.o, so.data(), so.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(P.in.d, sd.data(), sd.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(P.in.rng, rng.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(P.in.pid, ident.data(), n * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(ctl, &ctl0, sizeof ctl0, hipMemcpyHostToDevice, c->stream));
-  r = launch_intersect(c, P, ctl, c->d_q0.as<uint32_t>(), (uint32_t)n);
+  r = launch_intersect(c, P, ctl, (uint32_t)n);
   if (r) return r;
   HIP_TRY(c, c->d_scratch.ensure(n * sizeof(HitOut)));
   hipLaunchKernelGGL(k_resolve_hits, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->S, P, (uint32_t)n, c->d_scratch.as<HitOut>());
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(out, c->d_scratch.p, n * sizeof(HitOut), hipMemcpyDeviceToHost, c->stream));
-  if (rng_inout) HIP_TRY(c, hipMemcpyAsync(rng_inout, P.rng, n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (rng_inout) HIP_TRY(c, hipMemcpyAsync(rng_inout, P.in.rng, n * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return PTMI_OK;
 }

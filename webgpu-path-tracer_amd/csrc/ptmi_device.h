@@ -105,22 +105,40 @@ struct DevScene {
   int light_quad;  // first quad with emission.x > 0 (common.wgsl:258-269), -1 if none
 };
 
-// ---- per-path state (arrays indexed by path id = frame_slot * npix + pixel) -----------------------------
+// ---- path state ----------------------------------------------------------------------------------------
+// Live state is indexed by QUEUE SLOT and compacted every step: step s reads the `in` buffers, k_shade writes the
+// survivors densely into the `out` buffers (= `in` of step s+1), so every kernel streams its state coalesced
+// instead of gathering by path id.  Slots can be holes (pid == PID_HOLE): a block of k_shade claims output space in
+// regions and marks what it did not use.  The hit record belongs to the slot of `in`.  Radiance (`acc`) stays
+// indexed by path id = frame_slot * n_local + local pixel index: it changes rarely (emissive hits, misses) and k_accumulate needs it
+// by pixel.
+constexpr uint32_t PID_HOLE = 0xffffffffu;
+constexpr uint32_t HITMAT_MISS = 0x0fffffffu;  // hitScene returned false (so far)
+constexpr uint32_t HITMAT_HOLE = 0x0ffffffeu;  // slot holds no path
+constexpr uint32_t HITMAT_BVH = 0x80000000u;   // flag: the ray entered the root box, k_bvh still has to traverse it
+constexpr uint32_t HITMAT_ID = 0x0fffffffu;
+
+struct Slots {
+  float4* o;      // {origin.xyz, -}
+  float4* d;      // {dir.xyz, -}
+  float4* thr;    // {T.xyz, bounce index as int bits}
+  uint32_t* rng;  // randState
+  uint32_t* pid;  // path id, or PID_HOLE
+};
 struct Paths {
-  float4* ray;      // 2 per path: {o.xyz, -} {d.xyz, -}
-  float4* thr;      // {T.xyz, bounce index as int bits}
-  float4* acc;      // {acc_radiance.xyz, sample index as int bits}; holds the final pixel colour at the end
-  float4* pixsum;   // {pixColor.xyz, -}  (num_samples > 1 only)
-  uint32_t* rng;    // randState
-  float4* hit;      // {t, u, v, kind<<28 | index}
-  uint32_t* hitmat; // effective material id (after hit_volume's clobber, Q3)
+  Slots in, out;
+  float4* hit;       // by slot of `in`: {t, u, v, kind<<28 | index}
+  uint32_t* hitmat;  // by slot of `in`: effective material id (after hit_volume's clobber, Q3) / MISS / HOLE
+  float4* acc;       // by path id: {acc_radiance.xyz, sample index as int bits}; the final pixel colour at the end
+  float4* pixsum;    // by path id: {pixColor.xyz, -}  (num_samples > 1 only)
+  uint32_t cap;      // slots per queue buffer
 };
 
 struct StepCtl {
-  uint32_t n_rays;  // entries in this step's ray queue
-  uint32_t n_bvh;   // entries of the BVH list (rays that entered the root box), written by k_prims
-  uint32_t head_b;  // next range of the BVH list for k_bvh
-  uint32_t head_s;  // next chunk for k_shade
+  uint32_t n_rays;   // slots of this step's queue (holes included)
+  uint32_t pad;
+  uint32_t head_b;   // next range of slots for k_bvh
+  uint32_t n_valid;  // slots that hold a path = hitScene invocations of this step (tallied by k_shade)
 };
 
 struct RenderConst {

@@ -17,45 +17,37 @@ namespace ptmi {
 
 constexpr int kBlock = 256;
 
-__global__ __launch_bounds__(kBlock) void k_generate(RenderConst rc, Paths P, uint32_t* __restrict__ q0, StepCtl* __restrict__ ctl) {
+__global__ __launch_bounds__(kBlock) void k_generate(RenderConst rc, Paths P, StepCtl* __restrict__ ctl) {
   uint32_t total = rc.n_local * (uint32_t)rc.n_frames;
   for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < total; g += gridDim.x * kBlock) {
     uint32_t f = g / rc.n_local, j = g - f * rc.n_local;
     uint32_t pix = local_to_pixel(rc, j);
-    uint32_t pid = f * rc.npix + pix;
+    uint32_t pid = g;  // path id = frame_slot * n_local + local pixel index (dense per rank)
     // u32(uniforms.frameNum): the frame number travels through an f32 uniform (renderer.js:173)
     uint32_t rng = pix + (uint32_t)(float)(rc.frame0 + f) * 719393u;
     f3 o, d;
     camera_ray(rc, pix, 0, rng, o, d);
-    P.ray[2 * (size_t)pid] = make_float4(o.x, o.y, o.z, 0.0f);
-    P.ray[2 * (size_t)pid + 1] = make_float4(d.x, d.y, d.z, 0.0f);
-    P.thr[pid] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0));
+    P.in.o[g] = make_float4(o.x, o.y, o.z, 0.0f);
+    P.in.d[g] = make_float4(d.x, d.y, d.z, 0.0f);
+    P.in.thr[g] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0));
+    P.in.rng[g] = rng;
+    P.in.pid[g] = pid;
     P.acc[pid] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(0));
     if (P.pixsum) P.pixsum[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    P.rng[pid] = rng;
-    q0[g] = pid;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) ctl[0].n_rays = total;
 }
 
-// Work distribution (both k_intersect and k_shade): the step's ray queue is cut into chunks of kChunk
-// entries.  A block claims a chunk with ONE global atomic, its waves pull 64-entry sub-chunks from an
-// LDS counter, and all queue bookkeeping (sorting by material class, compaction of survivors) happens
-// in LDS.  Same-address global atomics cost ~11 ns each on MI355X, so per-wave global atomics would
-// cap a step at ~90 M rays/s per counter; per-chunk atomics are 32x rarer and off the critical path.
 constexpr int kChunk = 2048;
-// Small queues (the Russian-roulette tail of a batch) use smaller chunks so that the work still
-// spreads over ~target_blocks blocks instead of a few blocks walking 2048 rays each.
-DEV uint32_t chunk_size_for(uint32_t n, uint32_t target_blocks) {
-  uint32_t c = (n / target_blocks + 255u) & ~255u;
-  return min((uint32_t)kChunk, max(256u, c));
-}
 
-DEV int bin_of(const DevScene& S, uint32_t prim, int mat) {
-  if ((prim >> 28) == K_NONE) return BIN_MISS;
-  float ty = S.mats[4 * mat + 3].z;
-  return (ty == 0.0f) ? BIN_LAMBERTIAN : (ty == 1.0f) ? BIN_MIRROR : (ty == 2.0f) ? BIN_GLASS : (ty == 3.0f) ? BIN_ISOTROPIC : BIN_OTHER;
-}
+// 96 VGPRs (5 waves/SIMD, no spills) measured 27 % faster than the compiler's default 106 VGPRs / 4 waves: the kernel
+// is latency bound; 6 and 8 waves/SIMD spill and lose again.
+#ifndef PTMI_SHADE_ATTR
+#define PTMI_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(5, 8)))
+#endif
+#ifndef PTMI_BVH_ATTR
+#define PTMI_BVH_ATTR __attribute__((amdgpu_waves_per_eu(4, 8)))
+#endif
 
 // Rank of this lane's entry within its material bin for the current chunk (counting sort, pass 1).
 // Must be called from wave-uniform control flow; lanes without an entry pass bin = -1.
@@ -76,66 +68,42 @@ DEV uint32_t bin_rank(int bin, uint32_t* s_cnt) {
   return rank;
 }
 
-// hitScene, part 1 (hitRay.wgsl:6-54): spheres, quads and the ROOT box test for every ray of the step's queue.
-// Coherent work (the primitive tables sit in SGPRs); rays that do not enter the root box are final, the others
-// are appended to the step's BVH list (staged in LDS, one global atomic per 2048-ray chunk).
+// hitScene, part 1 (hitRay.wgsl:6-54): spheres, quads and the ROOT box test for every slot of the step's queue.
+// Purely element-wise: one slot per thread, state streamed by slot, primitive tables in SGPRs, no LDS, no atomics —
+// latency is hidden by sheer parallelism.  A ray that enters the root box gets HITMAT_BVH set in its hitmat word;
+// k_bvh finds its work by scanning those flags.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_prims(DevScene S, Paths P, StepCtl* __restrict__ ctl, const uint32_t* __restrict__ queue,
-                                                  uint32_t* __restrict__ bvh_list, unsigned long long* __restrict__ totals) {
-  __shared__ uint32_t s_list[kChunk];
-  __shared__ uint32_t s_n, s_base;
-  const int lane = lane_id();
+__global__ __launch_bounds__(kBlock) void k_prims(DevScene S, Paths P, const StepCtl* __restrict__ ctl, unsigned long long* __restrict__ totals) {
   const uint32_t n = ctl->n_rays;
   const bool have_bvh = S.n_nodes > 0;
   Counters cn = {0, 0, 0, 0, 0};
-  for (uint32_t base = blockIdx.x * (uint32_t)kChunk; base < n; base += gridDim.x * (uint32_t)kChunk) {
-    const uint32_t m = min((uint32_t)kChunk, n - base);
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    for (uint32_t j0 = (threadIdx.x & ~63u); j0 < m; j0 += kBlock) {
-      const uint32_t j = j0 + lane;
-      bool to_bvh = false;
-      uint32_t pid = 0;
-      if (j < m) {
-        pid = queue[base + j];
-        float4 r0 = P.ray[2 * (size_t)pid], r1 = P.ray[2 * (size_t)pid + 1];
-        f3 o = mk3(r0), d = mk3(r1);
-        Closest c;
-        c.t = kMaxFloat;
-        c.u = c.v = 0.0f;
-        c.prim = K_NONE;
-        c.mat = 0;
-        if (S.n_spheres > 0) {
-          uint32_t rng = P.rng[pid];
-          uint32_t rng0 = rng;
-          hit_spheres<COUNT>(S, o, d, rng, c, cn);
-          if (rng != rng0) P.rng[pid] = rng;
-        }
-        hit_quads<COUNT>(S, o, d, c, cn);
-        if (have_bvh) {
-          if (COUNT) cn.node_visits++;
-          const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-          to_bvh = hit_aabb(S.root_lo, S.root_hi, c.t, o, inv);
-        }
-        P.hit[pid] = make_float4(c.t, c.u, c.v, __uint_as_float(c.prim));
-        P.hitmat[pid] = ((c.prim >> 28) != K_NONE) ? (uint32_t)c.mat : 0xffffffffu;
-      }
-      const uint64_t lm = __ballot(to_bvh);
-      if (lm) {
-        const int leader = __ffsll((unsigned long long)lm) - 1;
-        uint32_t lb = 0;
-        if (lane == leader) lb = atomicAdd(&s_n, (uint32_t)__popcll(lm));
-        lb = (uint32_t)__shfl((int)lb, leader, 64);
-        if (to_bvh) s_list[lb + lanes_below(lm)] = pid;
-      }
+  for (uint32_t slot = blockIdx.x * kBlock + threadIdx.x; slot < n; slot += gridDim.x * kBlock) {
+    const uint32_t pid = P.in.pid[slot];
+    if (pid == PID_HOLE) {
+      P.hitmat[slot] = HITMAT_HOLE;
+      continue;
     }
-    __syncthreads();
-    const uint32_t cnt = s_n;
-    if (threadIdx.x == 0 && cnt) s_base = atomicAdd(&ctl->n_bvh, cnt);
-    __syncthreads();
-    const uint32_t ob = s_base;
-    for (uint32_t j = threadIdx.x; j < cnt; j += kBlock) bvh_list[ob + j] = s_list[j];
-    __syncthreads();
+    f3 o = mk3(P.in.o[slot]), d = mk3(P.in.d[slot]);
+    Closest c;
+    c.t = kMaxFloat;
+    c.u = c.v = 0.0f;
+    c.prim = K_NONE;
+    c.mat = 0;
+    if (S.n_spheres > 0) {
+      uint32_t rng = P.in.rng[slot];
+      uint32_t rng0 = rng;
+      hit_spheres<COUNT>(S, o, d, rng, c, cn);
+      if (rng != rng0) P.in.rng[slot] = rng;
+    }
+    hit_quads<COUNT>(S, o, d, c, cn);
+    bool to_bvh = false;
+    if (have_bvh) {
+      if (COUNT) cn.node_visits++;
+      const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+      to_bvh = hit_aabb(S.root_lo, S.root_hi, c.t, o, inv);
+    }
+    P.hit[slot] = make_float4(c.t, c.u, c.v, __uint_as_float(c.prim));
+    P.hitmat[slot] = (((c.prim >> 28) != K_NONE) ? (uint32_t)c.mat : HITMAT_MISS) | (to_bvh ? HITMAT_BVH : 0u);
   }
   if (COUNT) {
     uint32_t v[5] = {cn.node_visits, cn.tri_tests, cn.sphere_tests, cn.quad_tests, cn.mat_fetches};
@@ -143,38 +111,41 @@ __global__ __launch_bounds__(kBlock) void k_prims(DevScene S, Paths P, StepCtl* 
     for (int k = 0; k < 5; k++) {
       unsigned long long x = v[k];
       for (int off2 = 32; off2 > 0; off2 >>= 1) x += __shfl_down(x, off2, 64);
-      if (lane == 0 && x) atomicAdd(&totals[2 + k], x);
+      if (lane_id() == 0 && x) atomicAdd(&totals[2 + k], x);
     }
   }
 }
 
-// A wave refills its idle lanes from its range of the BVH list once this many lanes are idle (or all are).
+// A wave refills its idle lanes once this many lanes are idle (or all are).
 constexpr int kRefillThreshold = 16;
-constexpr uint32_t kBvhRange = 512;  // list entries a wave claims per global atomic (less when the list is short)
+constexpr uint32_t kBvhRange = 2048;  // slots a wave claims per global atomic (less when the queue is short)
 
-// hitScene, part 2 (hitRay.wgsl:42-110): BVH traversal of the listed rays by persistent, barrier-free waves.
-// One block = one wave, so LDS (the traversal stacks, stack_alloc x 512 B per wave) is the only thing that limits
-// how many waves a CU holds.  Each lane runs the traversal state machine on one ray; when kRefillThreshold lanes
-// have finished, the wave refills them (ballot) from the range of the list it has claimed (one global atomic per
-// kBvhRange rays), so short rays never leave lanes idle behind a long one and tails exist only at kernel end.
-//   FLAT = false (BVH fits the caches, VALU bound): while-while — inner steps and triangle tests run in
-//   separate loops so that each runs with as many lanes as possible.
-//   FLAT = true (large BVH, latency bound): one 64-byte record fetch per lane per iteration.
+// hitScene, part 2 (hitRay.wgsl:42-110): BVH traversal by persistent, barrier-free waves.
+// One block = one wave, so LDS (the traversal stacks, stack_alloc x 512 B per wave, plus a 64-entry candidate
+// buffer) is the only thing that limits how many waves a CU holds.  A wave claims ranges of queue SLOTS (one global
+// atomic per <= 2048 slots), scans the HITMAT_BVH flags 64 slots at a time into its candidate buffer, and hands
+// candidates to idle lanes: each lane runs the traversal state machine on one ray, and whenever kRefillThreshold
+// lanes have finished they are refilled, so short rays never leave lanes idle behind a long one and tails exist only
+// at kernel end.
+//   FLAT = true  one 64-byte record fetch (pair or triangle) per lane per iteration — the default.
+//   FLAT = false while-while: inner steps and triangle tests in separate loops (kept for A/B runs).
 template <bool COUNT, bool FLAT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_bvh(DevScene S, Paths P, StepCtl* __restrict__ ctl,
-                                                                                       const uint32_t* __restrict__ bvh_list, int stack_size,
-                                                                                       int refill_threshold, unsigned long long* __restrict__ totals) {
+__global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, StepCtl* __restrict__ ctl, int stack_size,
+                                                                                       int stack_alloc, int refill_threshold,
+                                                                                       unsigned long long* __restrict__ totals) {
   extern __shared__ int lds_stack[];
   const int lane = lane_id();
   int* stk = lds_stack + lane;
-  const uint32_t n = ctl->n_bvh;
-  // short lists (the Russian-roulette tail) are cut into smaller ranges so that they still spread over all waves
+  uint32_t* cand = reinterpret_cast<uint32_t*>(lds_stack + stack_alloc * 2 * 64);  // [128] candidate slots
+  const uint32_t n = ctl->n_rays;
+  // short queues (the Russian-roulette tail) are cut into smaller ranges so that they still spread over all waves
   const uint32_t range = min(kBvhRange, max(64u, ((n / (2u * gridDim.x)) + 63u) & ~63u));
   Counters cn = {0, 0, 0, 0, 0};
-  uint32_t rb = 0, re = 0;  // this wave's claimed range of the list (wave-uniform)
+  uint32_t rb = 0, re = 0;   // this wave's claimed range of slots still to be scanned (wave-uniform)
+  uint32_t ncand = 0;        // candidates waiting in `cand` (wave-uniform)
   bool exhausted = (n == 0);
   bool has = false;
-  uint32_t mypid = 0;
+  uint32_t myslot = 0;
   Trav t;
   t.cur = T_DONE;
   t.pending = 0;
@@ -188,39 +159,49 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   for (;;) {
     // retire finished rays (stores only: nothing here waits on memory)
     if (has && t.cur == T_DONE && t.pending == 0u) {
-      P.hit[mypid] = make_float4(t.c.t, t.c.u, t.c.v, __uint_as_float(t.c.prim));
-      P.hitmat[mypid] = ((t.c.prim >> 28) != K_NONE) ? (uint32_t)t.c.mat : 0xffffffffu;
+      P.hit[myslot] = make_float4(t.c.t, t.c.u, t.c.v, __uint_as_float(t.c.prim));
+      P.hitmat[myslot] = ((t.c.prim >> 28) != K_NONE) ? (uint32_t)t.c.mat : HITMAT_MISS;
       has = false;
     }
     uint64_t hm = __ballot(has);
     int nact = __popcll(hm);
     if ((64 - nact) >= (nact == 0 ? 1 : refill_threshold)) {
-      if (rb == re && !exhausted) {  // claim the next range
-        uint32_t nb = 0;
-        if (lane == 0) nb = atomicAdd(&ctl->head_b, range);
-        nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
-        if (nb >= n) {
-          exhausted = true;
-        } else {
+      const uint32_t want = (uint32_t)(64 - nact);
+      // top up the candidate buffer: scan 64 slots at a time until it holds enough or the queue is exhausted
+      while (ncand < want && !(exhausted && rb == re)) {
+        if (rb == re) {  // claim the next range of slots
+          uint32_t nb = 0;
+          if (lane == 0) nb = atomicAdd(&ctl->head_b, range);
+          nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+          if (nb >= n) {
+            exhausted = true;
+            continue;
+          }
           rb = nb;
           re = min(nb + range, n);
         }
+        const uint32_t slot = rb + (uint32_t)lane;
+        const bool flagged = slot < re && (P.hitmat[slot] & HITMAT_BVH) != 0u;
+        const uint64_t fm = __ballot(flagged);
+        if (flagged) cand[ncand + lanes_below(fm)] = slot;
+        ncand += (uint32_t)__popcll(fm);
+        rb = min(rb + 64u, re);
       }
-      const uint32_t avail = re - rb;
-      if (avail) {
+      if (ncand) {
         const uint64_t idle = ~hm;
         const uint32_t k = lanes_below(idle);
-        if (!has && k < avail) {
-          mypid = bvh_list[rb + k];
-          float4 r0 = P.ray[2 * (size_t)mypid], r1 = P.ray[2 * (size_t)mypid + 1];
-          float4 h = P.hit[mypid];
-          const uint32_t hmat = P.hitmat[mypid];
+        const uint32_t take = min(ncand, want);
+        if (!has && k < take) {
+          myslot = cand[ncand - 1u - k];
+          float4 r0 = P.in.o[myslot], r1 = P.in.d[myslot];
+          float4 h = P.hit[myslot];
+          const uint32_t hmat = P.hitmat[myslot] & HITMAT_ID;
           t.o = mk3(r0);
           t.d = mk3(r1);
           t.inv = mk3(1.0f / t.d.x, 1.0f / t.d.y, 1.0f / t.d.z);
           t.negmask = (t.d.x < 0 ? 1u : 0u) | (t.d.y < 0 ? 2u : 0u) | (t.d.z < 0 ? 4u : 0u);
           t.c.t = h.x, t.c.u = h.y, t.c.v = h.z, t.c.prim = __float_as_uint(h.w);
-          t.c.mat = (hmat != 0xffffffffu) ? (int)hmat : 0;
+          t.c.mat = (hmat != HITMAT_MISS) ? (int)hmat : 0;
           t.orr.mesh = -1;
           t.sp = 0;
           if (root & REF_LEAF) {
@@ -232,16 +213,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
           }
           has = true;
         }
-        rb += min(avail, (uint32_t)(64 - nact));
+        ncand -= take;
         hm = __ballot(has);
         nact = __popcll(hm);
       }
     }
-    if (nact == 0) {
-      if (exhausted) break;
-      continue;  // range was empty: claim the next one
-    }
-    const bool more = !(exhausted && rb == re);
+    if (nact == 0) break;  // nothing in flight, nothing buffered, queue exhausted
+    const bool more = ncand > 0 || !(exhausted && rb == re);
     const int min_working = more ? (64 - refill_threshold + 1) : 1;
     int working;
     if (FLAT) {
@@ -275,29 +253,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   }
 }
 
+// What a surviving path carries into the next step's queue.
+struct NewState {
+  f3 o, d, T;
+  int bounce;
+  uint32_t rng, pid;
+};
+
 // One path's iteration of the `for i < MAX_BOUNCES` loop body after hitScene (traceRay.wgsl:10-80).
-// Returns true when the path continues with a new ray (already stored), false when this slot is done.
+// Returns true when the path continues (its state for the next step is in `ns`), false when the slot is done.
+// `acc` (by path id) is touched only when it changes or is needed: `acc + emission*T` with emission*T == +-0
+// is `acc` bit for bit (acc is never -0: it starts at +0 and x + y = -0 only for x = y = -0), and with
+// NUM_SAMPLES == 1 the pixel colour (0 + acc) / 1 is `acc` itself.
 template <bool IS>
-DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, uint32_t pid, const QuadL& L) {
-  float4 r0 = P.ray[2 * (size_t)pid], r1 = P.ray[2 * (size_t)pid + 1];
-  f3 o = mk3(r0), d = mk3(r1);
-  float4 T4 = P.thr[pid], A4 = P.acc[pid];
-  f3 T = mk3(T4), acc = mk3(A4);
-  int bounce = __float_as_int(T4.w), sample = __float_as_int(A4.w);
-  uint32_t rng = P.rng[pid];
+DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, uint32_t slot, const QuadL& L, NewState& ns) {
+  const uint32_t pid = P.in.pid[slot];
+  const f3 o = mk3(P.in.o[slot]), d = mk3(P.in.d[slot]);
+  const float4 T4 = P.in.thr[slot];
+  f3 T = mk3(T4);
+  int bounce = __float_as_int(T4.w);
+  uint32_t rng = P.in.rng[slot];
+  const float4 h = P.hit[slot];
 
   bool sample_done = false;
-  f3 radiance = acc;
+  bool drop_acc = false;     // the sample's radiance is `add` alone (importance-sampling early return, Q8)
+  f3 add = mk3(0, 0, 0);     // what this iteration adds to acc_radiance
   f3 no = o, nd = d;
-  const float4 h = P.hit[pid];
 
   if ((__float_as_uint(h.w) >> 28) == K_NONE) {  // traceRay.wgsl:12-16
-    radiance = acc + (mk3(rc.bg[0], rc.bg[1], rc.bg[2]) * T);
+    add = mk3(rc.bg[0], rc.bg[1], rc.bg[2]) * T;
     sample_done = true;
   } else {
-    int mat = (int)P.hitmat[pid];
+    int mat = (int)(P.hitmat[slot] & HITMAT_ID);
     Material m = load_material(S, mat);
-    // the queue is sorted by this class within each chunk, so `bin` is wave-uniform almost everywhere
+    // the chunk is sorted by this class, so `bin` is wave-uniform almost everywhere
     const int bin = (m.type == 0.0f) ? BIN_LAMBERTIAN : (m.type == 1.0f) ? BIN_MIRROR : (m.type == 2.0f) ? BIN_GLASS : (m.type == 3.0f) ? BIN_ISOTROPIC : BIN_OTHER;
     HitGeom g = resolve_hit(S, o, d, h.x, h.y, h.z, __float_as_uint(h.w));
     f3 emission = m.emission;
@@ -308,9 +297,9 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, uin
     f3 sdir = material_scatter(bin, m, g, d, rng, doSpecular, skip_pdf, unit_w);
     f3 sorg = (bin == BIN_OTHER) ? mk3(0, 0, 0) : g.p;
     bool roulette = true;
+    add = emission * T;  // acc_radiance += emissionColor * throughput (traceRay.wgsl:26,55,64)
     if (IS) {  // traceRay.wgsl:24-58
       if (skip_pdf) {
-        acc = acc + emission * T;
         T = T * mix3(m.color, m.spec, doSpecular);
         no = sorg;
         nd = sdir;
@@ -334,17 +323,15 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, uin
         float lpdf = light_pdf(L, so, sd);
         float pdf = 0.2f * lpdf + 0.8f * lambertian_pdf;
         if (pdf <= 0.00001f) {  // returns emission*throughput, dropping acc (Q8)
-          radiance = emission * T;
+          drop_acc = true;
           sample_done = true;
         } else {
-          acc = acc + emission * T;
           T = T * ((lambertian_pdf * mix3(m.color, m.spec, doSpecular)) / pdf);
           no = so;
           nd = sd;
         }
       }
     } else {  // traceRay.wgsl:61-68
-      acc = acc + emission * T;
       T = T * mix3(m.color, m.spec, doSpecular);
       no = sorg;
       nd = sdir;
@@ -362,36 +349,43 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, uin
         bounce++;
         if (bounce >= rc.max_bounces) sample_done = true;  // loop exhausted: returns acc (Q8)
       }
-      radiance = acc;
     }
   }
 
+  const bool changes = !(add.x == 0.0f && add.y == 0.0f && add.z == 0.0f);  // NaN counts as a change
+  ns.pid = pid;
   if (!sample_done) {
-    P.ray[2 * (size_t)pid] = make_float4(no.x, no.y, no.z, 0.0f);
-    P.ray[2 * (size_t)pid + 1] = make_float4(nd.x, nd.y, nd.z, 0.0f);
-    P.thr[pid] = make_float4(T.x, T.y, T.z, __int_as_float(bounce));
-    P.acc[pid] = make_float4(acc.x, acc.y, acc.z, __int_as_float(sample));
-    P.rng[pid] = rng;
+    if (changes) {
+      float4 A4 = P.acc[pid];
+      f3 acc = mk3(A4) + add;
+      P.acc[pid] = make_float4(acc.x, acc.y, acc.z, A4.w);
+    }
+    ns.o = no, ns.d = nd, ns.T = T, ns.bounce = bounce, ns.rng = rng;
     return true;
   }
 
-  // pathTrace (shootRay.wgsl:5-49): pixColor += ray_color(ray); next sample continues the same RNG stream
-  f3 sum = radiance;
-  if (rc.num_samples > 1) {
-    sum = mk3(P.pixsum[pid]) + radiance;
-  } else {
-    sum = mk3(0, 0, 0) + radiance;
+  // pathTrace (shootRay.wgsl:5-49): pixColor += ray_color(ray); pixColor /= NUM_SAMPLES
+  if (rc.num_samples == 1) {
+    if (drop_acc) {
+      f3 fin = (mk3(0, 0, 0) + add) / rc.sample_div;
+      P.acc[pid] = make_float4(fin.x, fin.y, fin.z, __int_as_float(1));
+    } else if (changes) {
+      float4 A4 = P.acc[pid];
+      f3 fin = (mk3(0, 0, 0) + (mk3(A4) + add)) / rc.sample_div;
+      P.acc[pid] = make_float4(fin.x, fin.y, fin.z, __int_as_float(1));
+    }  // else: (0 + acc) / 1 == acc, already in place
+    return false;
   }
+  float4 A4 = P.acc[pid];
+  int sample = __float_as_int(A4.w);
+  f3 radiance = drop_acc ? add : (mk3(A4) + add);
+  f3 sum = mk3(P.pixsum[pid]) + radiance;
   sample++;
-  if (sample < rc.num_samples) {
+  if (sample < rc.num_samples) {  // the next sample continues the same RNG stream in the same slot
     P.pixsum[pid] = make_float4(sum.x, sum.y, sum.z, 0.0f);
-    uint32_t pix = pid % rc.npix;
-    camera_ray(rc, pix, sample, rng, no, nd);
-    P.ray[2 * (size_t)pid] = make_float4(no.x, no.y, no.z, 0.0f);
-    P.ray[2 * (size_t)pid + 1] = make_float4(nd.x, nd.y, nd.z, 0.0f);
-    P.thr[pid] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0));
+    camera_ray(rc, local_to_pixel(rc, pid % rc.n_local), sample, rng, no, nd);
     P.acc[pid] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(sample));
-    P.rng[pid] = rng;
+    ns.o = no, ns.d = nd, ns.T = mk3(1.0f, 1.0f, 1.0f), ns.bounce = 0, ns.rng = rng;
     return true;
   }
   f3 fin = sum / rc.sample_div;
@@ -399,104 +393,158 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, uin
   return false;
 }
 
+constexpr int kSChunk = 512;  // slots a k_shade block sorts, shades and compacts at a time
+
+// ray_color's loop body for one step, 512 slots at a time per block:
+//   1  LDS counting sort of the chunk by the material class of each slot's hit (ballot ranks), so that the waves
+//      are (almost) uniform in the 4-way material switch of scatterRay.wgsl; holes drop out here;
+//   2  shade_one per slot (state streamed in by slot); survivors' next state is staged in LDS, densely;
+//   3  the staged states are copied to the block's current OUTPUT REGION of the next queue, coalesced.  A block
+//      claims a region with one global atomic (16 or so per launch), fills it across chunks — an entry that does
+//      not fit any more continues in the next region — and marks what is left at the end as holes.
 template <bool IS>
-__global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, const uint32_t* __restrict__ queue,
-                                                  uint32_t* __restrict__ q_next, uint32_t target_blocks) {
-  __shared__ uint32_t s_out[kChunk];     // survivors of the chunk
-  __shared__ uint32_t s_sorted[kChunk];  // the chunk's path ids grouped by material class
+__global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, unsigned long long* __restrict__ totals) {
+  __shared__ float4 s_o[kSChunk], s_d[kSChunk], s_thr[kSChunk];
+  __shared__ uint32_t s_rng[kSChunk], s_pid[kSChunk];
+  __shared__ uint16_t s_sorted[kSChunk];
   __shared__ uint32_t s_cnt[NUM_BINS + 2];
-  __shared__ uint32_t s_chunk, s_next, s_nout, s_base;
+  __shared__ uint32_t s_nout, s_next, s_cursor, s_rend, s_b0, s_n0, s_b1;
   const QuadL L = load_light(S);
   const int lane = lane_id();
   const uint32_t n = ctl->n_rays;
-  const uint32_t csz = chunk_size_for(n, target_blocks);
-  while (true) {
-    if (threadIdx.x == 0) {
-      s_chunk = atomicAdd(&ctl->head_s, 1u);
-      s_next = 0;
-      s_nout = 0;
-    }
+  // region size: a block handles about n / gridDim slots per launch; 1/16 of that per claim keeps both the
+  // number of atomics and the holes left at the end (at most one region per block) small
+  const uint32_t region = max((uint32_t)kSChunk, ((n / gridDim.x / 16u) + 511u) & ~511u);
+  if (threadIdx.x == 0) {
+    s_cursor = 0;
+    s_rend = 0;
+  }
+  uint32_t my_valid = 0;  // thread 0: slots holding a path seen by this block (= hitScene invocations)
+  for (uint32_t base = blockIdx.x * (uint32_t)kSChunk; base < n; base += gridDim.x * (uint32_t)kSChunk) {
+    const uint32_t m = min((uint32_t)kSChunk, n - base);
     if (threadIdx.x < NUM_BINS) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+      s_nout = 0;
+      s_next = 0;
+    }
     __syncthreads();
-    const uint32_t base = s_chunk * csz;
-    if (base >= n) break;
-    const uint32_t m = min(csz, n - base);
-    // prologue: counting sort of the chunk by the material class of each path's hit (ballot ranks + LDS
-    // counters), so that the waves below are (almost) uniform in the 4-way material switch of scatterRay.wgsl
-    uint32_t keys[kChunk / kBlock];
-    uint32_t pids[kChunk / kBlock];
+    // ---- 1: sort ----
+    uint32_t keys[kSChunk / kBlock];
 #pragma unroll
-    for (int r = 0; r < kChunk / kBlock; r++) {
+    for (int r = 0; r < kSChunk / kBlock; r++) {
       const uint32_t j = (uint32_t)r * kBlock + threadIdx.x;
       int bin = -1;
-      pids[r] = 0;
       if (j < m) {
-        const uint32_t pid = queue[base + j];
-        pids[r] = pid;
-        const uint32_t hmat = P.hitmat[pid];
-        if (hmat == 0xffffffffu) {
+        const uint32_t hmat = P.hitmat[base + j] & HITMAT_ID;
+        if (hmat == HITMAT_MISS) {
           bin = BIN_MISS;
-        } else {
+        } else if (hmat != HITMAT_HOLE) {
           const float ty = S.mats[4 * (int)hmat + 3].z;
           bin = (ty == 0.0f) ? BIN_LAMBERTIAN : (ty == 1.0f) ? BIN_MIRROR : (ty == 2.0f) ? BIN_GLASS : (ty == 3.0f) ? BIN_ISOTROPIC : BIN_OTHER;
         }
       }
-      const bool any = (uint32_t)r * kBlock < m;  // block-uniform: skip empty rounds of small chunks
       uint32_t rank = 0;
-      if (any) rank = bin_rank(bin, s_cnt);
-      keys[r] = (uint32_t)(bin & 7) | (rank << 3);
+      if ((uint32_t)r * kBlock < m) rank = bin_rank(bin, s_cnt);  // block-uniform condition
+      keys[r] = (bin < 0) ? 0xffffffffu : ((uint32_t)bin | (rank << 3));
     }
     __syncthreads();
+    uint32_t nvalid = 0;
     {
       uint32_t off[NUM_BINS];
-      uint32_t run = 0;
 #pragma unroll
       for (int b = 0; b < NUM_BINS; b++) {
-        off[b] = run;
-        run += s_cnt[b];
+        off[b] = nvalid;
+        nvalid += s_cnt[b];
       }
 #pragma unroll
-      for (int r = 0; r < kChunk / kBlock; r++) {
-        const uint32_t j = (uint32_t)r * kBlock + threadIdx.x;
-        if (j < m) {
+      for (int r = 0; r < kSChunk / kBlock; r++) {
+        if (keys[r] != 0xffffffffu) {
           const uint32_t b = keys[r] & 7u;
           uint32_t o = off[0];
 #pragma unroll
           for (int k = 1; k < NUM_BINS; k++) o = (b == (uint32_t)k) ? off[k] : o;
-          s_sorted[o + (keys[r] >> 3)] = pids[r];
+          s_sorted[o + (keys[r] >> 3)] = (uint16_t)((uint32_t)r * kBlock + threadIdx.x);
         }
       }
     }
+    my_valid += nvalid;
     __syncthreads();
-    while (true) {
-      uint32_t sub = 0;
-      if (lane == 0) sub = atomicAdd(&s_next, 64u);
-      sub = (uint32_t)__builtin_amdgcn_readfirstlane((int)sub);
-      if (sub >= m) break;
-      const uint32_t j = sub + lane;
+    // ---- 2: shade, stage survivors ----
+    // waves take 64-entry groups dynamically: the sort puts the cheap MISS entries last, static rounds would leave
+    // the waves that got them idle at the barrier
+#pragma unroll 1
+    for (;;) {
+      uint32_t k0 = 0;
+      if (lane == 0) k0 = atomicAdd(&s_next, 64u);
+      k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)k0);
+      if (k0 >= nvalid) break;
+      const uint32_t k = k0 + lane;
       bool survive = false;
-      uint32_t pid = 0;
-      if (j < m) {
-        pid = s_sorted[j];
-        survive = shade_one<IS>(S, rc, P, pid, L);
-      }
+      NewState ns;
+      ns.o = ns.d = ns.T = mk3(0, 0, 0);
+      ns.bounce = 0, ns.rng = 0, ns.pid = 0;
+      if (k < nvalid) survive = shade_one<IS>(S, rc, P, base + s_sorted[k], L, ns);
       const uint64_t mk = __ballot(survive);
       if (mk) {
         const int leader = __ffsll((unsigned long long)mk) - 1;
         uint32_t bb = 0;
         if (lane == leader) bb = atomicAdd(&s_nout, (uint32_t)__popcll(mk));
         bb = (uint32_t)__shfl((int)bb, leader, 64);
-        if (survive) s_out[bb + lanes_below(mk)] = pid;
+        if (survive) {
+          const uint32_t q = bb + lanes_below(mk);
+          s_o[q] = make_float4(ns.o.x, ns.o.y, ns.o.z, 0.0f);
+          s_d[q] = make_float4(ns.d.x, ns.d.y, ns.d.z, 0.0f);
+          s_thr[q] = make_float4(ns.T.x, ns.T.y, ns.T.z, __int_as_float(ns.bounce));
+          s_rng[q] = ns.rng;
+          s_pid[q] = ns.pid;
+        }
       }
     }
     __syncthreads();
-    const uint32_t nout = s_nout;
-    if (threadIdx.x == 0 && nout) s_base = atomicAdd(&ctl[1].n_rays, nout);
+    // ---- 3: place the survivors in the next queue ----
+    const uint32_t cnt = s_nout;
+    if (threadIdx.x == 0) {
+      uint32_t cur = s_cursor, rend = s_rend;
+      const uint32_t n0 = min(cnt, rend - cur);  // what still fits the current region
+      s_b0 = cur;
+      s_n0 = n0;
+      cur += n0;
+      if (cnt > n0) {  // claim the next region for the rest
+        const uint32_t want = max(region, cnt - n0);
+        uint32_t nb = atomicAdd(&ctl[1].n_rays, want);
+        if (nb + want > P.cap) {  // cannot happen with the host's sizing; never write out of bounds
+          atomicAdd(&totals[15], 1ull);
+          nb = 0;
+          s_n0 = 0;
+          s_b1 = 0xffffffffu;
+        } else {
+          s_b1 = nb;
+          cur = nb + (cnt - n0);
+          rend = nb + want;
+        }
+      }
+      s_cursor = cur;
+      s_rend = rend;
+    }
     __syncthreads();
-    const uint32_t ob = s_base;
-    for (uint32_t j = threadIdx.x; j < nout; j += kBlock) q_next[ob + j] = s_out[j];
+    {
+      const uint32_t b0 = s_b0, n0 = s_n0, b1 = s_b1;
+      for (uint32_t q = threadIdx.x; q < cnt; q += kBlock) {
+        if (q >= n0 && b1 == 0xffffffffu) break;
+        const uint32_t dst = (q < n0) ? (b0 + q) : (b1 + (q - n0));
+        P.out.o[dst] = s_o[q];
+        P.out.d[dst] = s_d[q];
+        P.out.thr[dst] = s_thr[q];
+        P.out.rng[dst] = s_rng[q];
+        P.out.pid[dst] = s_pid[q];
+      }
+    }
     __syncthreads();
   }
+  if (threadIdx.x == 0 && my_valid) atomicAdd(&ctl->n_valid, my_valid);
+  // what is left of the last region becomes holes
+  __syncthreads();
+  for (uint32_t i = s_cursor + threadIdx.x; i < s_rend; i += kBlock) P.out.pid[i] = PID_HOLE;
 }
 
 // main.wgsl:22-27 for all frame slots of the batch, in frame order; also tallies rays/paths.
@@ -507,7 +555,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(RenderConst rc, Paths P, 
     float4 cur = fb[pix];
     f3 c = mk3(cur);
     for (int f = 0; f < rc.n_frames; f++) {
-      float4 a = P.acc[(size_t)f * rc.npix + pix];
+      float4 a = P.acc[(size_t)f * rc.n_local + j];
       f3 col = mk3(a);
       if (f == 0 && rc.reset_first) {
         c = col;
@@ -519,7 +567,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(RenderConst rc, Paths P, 
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     unsigned long long rays = 0;
-    for (int s = 0; s < n_steps; s++) rays += ctl[s].n_rays;
+    for (int s = 0; s < n_steps; s++) rays += ctl[s].n_valid;
     totals[0] += rays;
     totals[1] += (unsigned long long)rc.n_local * (unsigned long long)rc.n_frames * (unsigned long long)rc.num_samples;
   }
@@ -547,13 +595,13 @@ __global__ __launch_bounds__(kBlock) void k_resolve_hits(DevScene S, Paths P, ui
   o.front_face = 0;
   o.hit = (prim >> 28) != K_NONE;
   if (o.hit) {
-    float4 r0 = P.ray[2 * (size_t)i], r1 = P.ray[2 * (size_t)i + 1];
+    float4 r0 = P.in.o[i], r1 = P.in.d[i];
     HitGeom g = resolve_hit(S, mk3(r0), mk3(r1), h.x, h.y, h.z, prim);
     o.t = h.x;
     o.p[0] = g.p.x, o.p[1] = g.p.y, o.p[2] = g.p.z;
     o.normal[0] = g.n.x, o.normal[1] = g.n.y, o.normal[2] = g.n.z;
     o.front_face = g.front ? 1 : 0;
-    const float4* m = S.mats + 4 * P.hitmat[i];
+    const float4* m = S.mats + 4 * (P.hitmat[i] & HITMAT_ID);
     for (int k = 0; k < 4; k++) {
       float4 v = m[k];
       o.material[4 * k] = v.x, o.material[4 * k + 1] = v.y, o.material[4 * k + 2] = v.z, o.material[4 * k + 3] = v.w;

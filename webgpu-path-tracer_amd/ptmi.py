@@ -238,8 +238,9 @@ class Context:
     def set_counters(self, on):
         self._ck(self.lib.ptmi_set_counters(self.h, int(on)))
 
-    def set_timing(self, on):
-        self._ck(self.lib.ptmi_set_timing(self.h, int(on)))
+    def set_timing(self, mode):
+        """0/False off, 1/True every kernel, 2 only k_bvh."""
+        self._ck(self.lib.ptmi_set_timing(self.h, int(mode)))
 
     def stats(self):
         s = Stats()
