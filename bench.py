@@ -35,7 +35,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"], help="c2 = BASELINE configs[1] (default, the metric's config); c3 = configs[2], dragon-class 871k triangles")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"],
+                    help="c2 = BASELINE configs[1] (default: the config the metric is quoted on); c3 = configs[2] dragon-class 871k tris; "
+                         "c4 = configs[3] sponza-class interior; c5 = configs[4] buddha-class + glass + importance sampling (use --width 3840 --height 2160)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=0, help="progressive frames per step and per GPU (0 = the config's: 64 for c2, 256 for c3)")
@@ -57,19 +59,28 @@ def main():
     torch.cuda.set_device(local)
 
     W, H = args.width, args.height
+    cam, extra = "cornell", {}
     if args.spp <= 0:
-        args.spp = 64 if args.workload == "c2" else 256
+        args.spp = {"c2": 64, "c3": 256, "c4": 512, "c5": 1024}[args.workload]
+    if args.workload == "c5" and args.bounces == 8:
+        args.bounces = 16
     spp = args.spp * world
     if args.workload == "c2":
         buffers = pkg.scenes.golden_buffers("c2")  # reference-generated buffers of configs[1] (tests/golden)
         label, stack = "configs[1]: Cornell + monkey_968.obj (967 tris)", args.stack_size or 20
-    else:
+    elif args.workload == "c3":
         buffers = pkg.scenes.c3_scene().buffers(native=pkg.ptmi.NativeHost())  # procedural stand-in, 871,414 tris
         label, stack = "configs[2]: Cornell + dragon-class mesh (871,414 tris, procedural stand-in for stanfordDragon.obj)", args.stack_size or 24
-    view = pkg.scenes.camera_view(*pkg.scenes.CAMERAS["cornell"])
+    elif args.workload == "c4":
+        buffers = pkg.scenes.c4_scene().buffers(native=pkg.ptmi.NativeHost())
+        label, stack, cam = "configs[3]: sponza-class interior (262,267 tris, procedural stand-in for sponzaAtrium.obj), camera inside", args.stack_size or 24, "interior"
+    else:
+        buffers = pkg.scenes.c5_scene().buffers(native=pkg.ptmi.NativeHost())
+        label, stack, extra = "configs[4]: Cornell + buddha-class glass mesh (1,087,716 tris, procedural stand-in for buddha.obj), importance sampling", args.stack_size or 24, dict(importance_sampling=1)
+    view = pkg.scenes.camera_view(*pkg.scenes.CAMERAS[cam])
     ctx = pkg.Context(local)
     ctx.upload_scene(buffers)
-    ctx.set_params(max_bounces=args.bounces, frames_in_flight=args.frames_in_flight, stack_size=stack)
+    ctx.set_params(max_bounces=args.bounces, frames_in_flight=args.frames_in_flight, stack_size=stack, **extra)
     ctx.resize(W, H)
     fb_t = None
     if world > 1:
@@ -172,11 +183,11 @@ def main():
 
             cores = min(ptm_oracle.max_threads(), args.cpu_threads)
             t = time.perf_counter()
-            _, ost = ptm_oracle.render(buffers, W, H, view, 1, 1, max_bounces=args.bounces, stack_size=stack, threads=cores)
+            _, ost = ptm_oracle.render(buffers, W, H, view, 1, 1, max_bounces=args.bounces, stack_size=stack, threads=cores, **extra)
             one = time.perf_counter() - t
             frames = int(max(1, min(args.spp, args.cpu_seconds / max(one, 1e-3))))
             t = time.perf_counter()
-            _, ost = ptm_oracle.render(buffers, W, H, view, 1, frames, max_bounces=args.bounces, stack_size=stack, threads=cores)
+            _, ost = ptm_oracle.render(buffers, W, H, view, 1, frames, max_bounces=args.bounces, stack_size=stack, threads=cores, **extra)
             cdt = time.perf_counter() - t
             out["cpu_baseline"] = {
                 "value": ost["rays"] / cdt / 1e6,

@@ -235,3 +235,26 @@ def test_dragon_class_scene_bit_exact(ctx, pkg, oracle):
         assert_same_bits(got, want, "c3 stack %d" % stack)
         for k in ("rays", "node_visits", "tri_tests", "quad_tests", "mat_fetches"):
             assert st[k] == ost[k], (stack, k)
+
+
+@pytest.mark.parametrize("name,cam,params", [
+    ("c4", "interior", dict(max_bounces=8, stack_size=24)),  # BASELINE configs[3]: sponza-class interior, camera inside
+    ("c5", "cornell", dict(max_bounces=16, stack_size=24, importance_sampling=1)),  # configs[4]: buddha-class, glass, IS
+])
+def test_large_procedural_scenes_bit_exact(ctx, pkg, oracle, name, cam, params):
+    b = getattr(pkg.scenes, name + "_scene")().buffers(native=pkg.ptmi.NativeHost())
+    assert b["triangles"].size // 24 == {"c4": 262267, "c5": 1087716}[name]
+    ctx.upload_scene(b)
+    ctx.set_params(**params)
+    ctx.resize(192, 108)
+    view = cornell_view(pkg, cam)
+    ctx.reset_stats()
+    ctx.set_counters(True)
+    ctx.render(view, 1, 2)
+    got = ctx.read_framebuffer()
+    st = ctx.stats()
+    ctx.set_counters(False)
+    want, ost = oracle.render(b, 192, 108, view, 1, 2, **params)
+    assert_same_bits(got, want, name)
+    for k in ("rays", "node_visits", "tri_tests", "quad_tests", "mat_fetches"):
+        assert st[k] == ost[k], (name, k)

@@ -241,3 +241,127 @@ def c3_scene(n_tris=871414, seed=1):
     """BASELINE configs[2]: Cornell walls/light + dragon-class mesh with the reference's dragon transform
     (lib/scene.js:216-220: scale 1.1, rotate pi/4 about y, translate (0.65,-0.64,0)) and dragonMat."""
     return mesh_scene(dragon_class_mesh(n_tris, seed), scale=(1.1, 1.1, 1.1), rotate=(math.pi / 4, [0, 1, 0]), translate=(0.65, -0.64, 0))
+
+
+def _grid_surface(P, wrap_u, wrap_v, flip=False):
+    """Triangulate a (nu, nv, 3) grid of points (2 triangles per cell) with smooth per-vertex normals from central
+    differences.  Returns (T,3,3) vertices and normals."""
+    nu, nv = P.shape[:2]
+    du = (np.roll(P, -1, 0) - np.roll(P, 1, 0)) if wrap_u else np.gradient(P, axis=0)
+    dv = (np.roll(P, -1, 1) - np.roll(P, 1, 1)) if wrap_v else np.gradient(P, axis=1)
+    N = np.cross(du, dv)
+    ln = np.linalg.norm(N, axis=2, keepdims=True)
+    N = N / np.where(ln == 0, 1.0, ln)
+    if flip:
+        N = -N
+    iu = np.arange(nu if wrap_u else nu - 1)[:, None]
+    iv = np.arange(nv if wrap_v else nv - 1)[None, :]
+    i1, j1 = (iu + 1) % nu, (iv + 1) % nv
+    order = (lambda a, b, c: (a, c, b)) if flip else (lambda a, b, c: (a, b, c))
+
+    def tris(A):
+        t1 = np.stack(order(A[iu, iv], A[i1, iv], A[i1, j1]), axis=2)
+        t2 = np.stack(order(A[iu, iv], A[i1, j1], A[iu, j1]), axis=2)
+        return np.stack([t1, t2], axis=2).reshape(-1, 3, 3)
+
+    return tris(P), tris(N)
+
+
+def _as_obj(parts, n_tris):
+    V = np.concatenate([p[0] for p in parts])[:n_tris]
+    N = np.concatenate([p[1] for p in parts])[:n_tris]
+    assert V.shape[0] == n_tris, (V.shape[0], n_tris)
+    return {"vertices": V.astype(np.float32).reshape(-1), "normals": N.astype(np.float32).reshape(-1)}
+
+
+def sponza_class_mesh(n_tris=262267, seed=2):
+    """Stand-in for sponzaAtrium.obj (absent): an interior — a room shell with inward normals, two rows of fluted
+    columns and a wavy drape — tessellated to EXACTLY n_tris triangles.  Fits [-1,1]^3; meant to be viewed from inside."""
+    r = _pcg_floats(seed, 16)
+    parts = []
+    per = n_tris / 10.0
+    # room shell: 6 finely tessellated faces, normals pointing inwards
+    k = max(2, int(math.sqrt(per * 3 / 6 / 2)))
+    a = np.linspace(-1, 1, k)
+    A, B = np.meshgrid(a, a, indexing="ij")
+    for axis, sign in ((0, -1), (0, 1), (1, -1), (1, 1), (2, -1), (2, 1)):
+        P = np.zeros((k, k, 3))
+        P[..., axis] = sign
+        P[..., (axis + 1) % 3] = A
+        P[..., (axis + 2) % 3] = B
+        parts.append(_grid_surface(P, False, False, flip=(sign > 0)))
+    # columns: fluted cylinders
+    ncol = 12
+    nu = max(8, int(math.sqrt(per * 6 / ncol / 2 * 2)))
+    nv = max(4, nu // 2)
+    u = np.linspace(0, 2 * math.pi, nu, endpoint=False)[:, None]
+    h = np.linspace(-1, 0.55, nv)[None, :]
+    for c in range(ncol):
+        cx = -0.62 if c % 2 == 0 else 0.62
+        cz = -0.85 + (c // 2) * 0.34
+        rad = 0.07 * (1 + 0.08 * np.cos(12 * u)) * (1 + 0.15 * np.exp(-((h - 0.5) / 0.05) ** 2) + 0.2 * np.exp(-((h + 0.95) / 0.05) ** 2))
+        P = np.stack([cx + rad * np.cos(u), np.broadcast_to(h, rad.shape), cz + rad * np.sin(u)], axis=-1)
+        parts.append(_grid_surface(P, True, False, flip=True))
+    # drape: fills the remaining triangle budget exactly
+    have = sum(p[0].shape[0] for p in parts)
+    rest = max(2, n_tris - have)
+    m = int(math.sqrt(rest / 2)) + 2
+    s = np.linspace(-0.55, 0.6, m)[:, None]   # height
+    t = np.linspace(-0.9, 0.9, m)[None, :]    # along the left wall
+    P = np.stack([-0.92 + 0.04 * np.sin(9 * s + 6.283 * r[0]) * np.cos(5 * t + 6.283 * r[1]) + 0 * t, s + 0 * t, t + 0 * s], axis=-1)
+    parts.append(_grid_surface(P, False, False))
+    return _as_obj(parts, n_tris)
+
+
+def buddha_class_mesh(n_tris=1087716, seed=3):
+    """Stand-in for buddha.obj (absent): a displaced, stacked-lobe solid of revolution tessellated to EXACTLY n_tris
+    triangles with smooth normals; longest extent 1."""
+    r = _pcg_floats(seed, 24)
+    quads = (n_tris + 1) // 2
+    nv = max(8, int(round(math.sqrt(quads / 2.0))))
+    nu = (quads + (nv - 1) - 1) // (nv - 1) + 1
+    u = np.linspace(0, 2 * math.pi, nu, endpoint=False)[:, None]
+    v = np.linspace(0.02, math.pi - 0.02, nv)[None, :]
+    prof = 0.30 + 0.12 * np.cos(3 * v) + 0.05 * np.cos(7 * v + 1.0)
+    bump = 1.0 + sum(0.03 * (0.5 + r[3 * k]) * np.sin((k + 3) * u + 6.283 * r[3 * k + 1]) * np.sin((2 * k + 2) * v + 6.283 * r[3 * k + 2]) for k in range(6))
+    rad = prof * bump * np.sin(v) ** 0.8
+    P = np.stack([rad * np.cos(u), -0.5 * np.cos(v) + 0 * u, rad * np.sin(u)], axis=-1)
+    lo, hi = P.reshape(-1, 3).min(0), P.reshape(-1, 3).max(0)
+    P = (P - (lo + hi) / 2) / (hi - lo).max()
+    return _as_obj([_grid_surface(P, True, False, flip=True)], n_tris)
+
+
+class InteriorScene(Scene):
+    """configs[3]: the mesh IS the room; one emissive quad under the ceiling (the light for importance sampling)."""
+
+    def __init__(self, mesh_data, material):
+        self._mesh, self._mat = mesh_data, material
+        super().__init__()
+
+    def create_spheres(self):
+        self.add_material("default", 0, [1, 0, 0], [0, 0, 0], [0, 0, 0], 0, 0, 0)
+        self.objs.extend(self.spheres)
+
+    def create_quads(self):
+        self.add_quad([-0.3, 0.98, -0.3], [0.6, 0, 0], [0, 0, 0.6], self.add_material("light", 0, [0, 0, 0], [0, 0, 0], [12, 12, 12], 0, 0, 0))
+        self.lights.append(self.quads[0])
+        self.objs.extend(self.quads)
+
+    def create_meshes(self):
+        self.add_mesh(self._mesh, self.add_material(*self._mat))
+        self._finish_meshes()
+
+
+def c4_scene(n_tris=262267, seed=2):
+    """BASELINE configs[3]: sponza-class interior, camera inside (CAMERAS['interior'])."""
+    return InteriorScene(sponza_class_mesh(n_tris, seed), ("stone", 0, [0.76, 0.70, 0.51], [0.76, 0.70, 0.51], [0, 0, 0], 0.05, 0.95, 0))
+
+
+def c5_scene(n_tris=1087716, seed=3):
+    """BASELINE configs[4]: Cornell box + buddha-class mesh with a GLASS material (eta 1.5); run with
+    importance_sampling=1, 16 bounces, stack_size 24."""
+    return mesh_scene(buddha_class_mesh(n_tris, seed), scale=(1.3, 1.3, 1.3), translate=(0.0, -0.35, 0.0),
+                      material=("glassBuddha", 2, [1, 1, 1], [0, 0, 0], [0, 0, 0], 0, 0, 1.5))
+
+
+CAMERAS["interior"] = ([0.0, -0.35, 0.92], [0.0, -0.2, -0.5])
