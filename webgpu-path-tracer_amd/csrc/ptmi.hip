@@ -442,7 +442,9 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
   const uint32_t want = (max_items + 63) / 64;
   const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(want, (uint32_t)c->num_cus * (uint32_t)waves_per_cu));
   const int thr = env_int("PTMI_REFILL", kRefillThreshold);
-#define PTMI_LAUNCH_BVH(CNT, FL) hipLaunchKernelGGL((k_bvh<CNT, FL>), dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->prm.stack_size, sa, thr, tot)
+  const int leaf_batch = env_int("PTMI_LEAF_BATCH", kLeafBatch);
+#define PTMI_LAUNCH_BVH(CNT, FL) \
+  hipLaunchKernelGGL((k_bvh<CNT, FL>), dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->prm.stack_size, sa, thr, leaf_batch, tot)
   if (c->counters) {
     if (flat) PTMI_LAUNCH_BVH(true, true);
     else PTMI_LAUNCH_BVH(true, false);

@@ -468,54 +468,12 @@ DEV void tri_record_test(const DevScene& S, int k, float4 t0, float4 t1, float4 
   if (COUNT) cn.mat_fetches++;
 }
 
-// Flat traversal iteration for the latency-bound regime (BVH larger than the caches): every lane fetches
-// exactly ONE 64-byte record — the pair record of its inner node or the pretri record of its pending
-// triangle, both 4 x float4 — so the wave pays one memory round trip per iteration and every lane advances by
-// one reference visit.  Failing stack entries are popped right away (LDS only), so that the next iteration
-// again has a record to fetch.  Visit order and outcomes are those of trav_step/visit_leaf.
-template <bool COUNT>
-DEV void trav_flat_iter(const DevScene& S, int stack_size, int* __restrict__ stk, Trav& t, Counters& cn) {
-  const bool leaf = t.pending != 0u;
-  const bool simple_leaf = leaf && !(t.pending & REF_MULTI);
-  if (leaf && !simple_leaf) {  // prim_count != 1 (external BVHs): rare, not unified
-    visit_leaf<COUNT>(S, t.pending, t.o, t.d, t.orr, t.c, cn);
-    t.pending = 0u;
-  } else if (leaf || t.cur < T_POP) {
-    const float4* rec = simple_leaf ? (S.pretri + 4 * (size_t)(t.pending & REF_IDX)) : (S.pairs + 4 * (size_t)t.cur);
-    const float4 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3v = rec[3];
-    if (simple_leaf) {
-      tri_record_test<COUNT>(S, (int)(t.pending & REF_IDX), f0, f1, f2, f3v, t, cn);
-      t.pending = 0u;
-    } else {
-      float tsL, tbL, tsR, tbR;
-      slab(f0, f1, t.o, t.inv, tsL, tbL);
-      slab(f2, f3v, t.o, t.inv, tsR, tbR);
-      const int axis = __float_as_int(f2.w);
-      const bool neg = ((t.negmask >> axis) & 1u) != 0u;
-      const uint32_t refL = __float_as_uint(f0.w), refR = __float_as_uint(f1.w);
-      const uint32_t nearRef = neg ? refR : refL;
-      uint32_t farRef = neg ? refL : refR;
-      const float tsN = neg ? tsR : tsL, tbN = neg ? tbR : tbL;
-      const float tsF = neg ? tsL : tsR, tbF = neg ? tbL : tbR;
-      const bool fB = tbF > tsF;
-      const bool fA = fB || (tbF != tbF);
-      farRef |= (fA ? REF_A : 0u) | (fB ? REF_B : 0u);
-      stk[(2 * t.sp) * 64] = (int)farRef;
-      stk[(2 * t.sp + 1) * 64] = __float_as_int(tsF);
-      t.sp++;
-      if (t.sp >= stack_size) {  // Q7
-        t.cur = T_DONE;
-        return;
-      }
-      if (COUNT) cn.node_visits++;
-      t.cur = T_POP;
-      if (ptm_min(t.c.t, tbN) > tsN) {
-        if (nearRef & REF_LEAF) t.pending = nearRef;
-        else t.cur = nearRef;
-      }
-    }
-  }
-  // pop until an entry passes or the stack is empty (LDS only)
+// Flat traversal: one 64-byte record fetch per lane per phase — the pair record of an inner node or the pretri
+// record of a pending triangle, both 4 x float4.  Failing stack entries are popped right away (LDS only), so that a
+// lane always has a record to fetch next.  Visit order and outcomes are those of trav_step/visit_leaf.
+// The two phases are separate functions so that the caller can run the (rarer) triangle phase only when enough
+// lanes wait for it: every phase costs its full instruction count however few lanes take part.
+DEV void trav_pop_until_pass(int* __restrict__ stk, Trav& t, Counters& cn, bool count) {
   while (t.cur == T_POP && t.pending == 0u) {
     if (t.sp == 0) {
       t.cur = T_DONE;
@@ -524,7 +482,7 @@ DEV void trav_flat_iter(const DevScene& S, int stack_size, int* __restrict__ stk
     t.sp--;
     const uint32_t e = (uint32_t)stk[(2 * t.sp) * 64];
     const float ts = __int_as_float(stk[(2 * t.sp + 1) * 64]);
-    if (COUNT) cn.node_visits++;
+    if (count) cn.node_visits++;
     const float ct = t.c.t;
     const bool pass = (ct != ct) ? ((e & REF_B) != 0u) : (((e & REF_A) != 0u) && (ct > ts));
     if (pass) {
@@ -532,6 +490,55 @@ DEV void trav_flat_iter(const DevScene& S, int stack_size, int* __restrict__ stk
       else t.cur = e & REF_IDX;
     }
   }
+}
+
+// lanes with a pending leaf: test its triangle(s), then pop
+template <bool COUNT>
+DEV void trav_leaf_phase(const DevScene& S, int* __restrict__ stk, Trav& t, Counters& cn) {
+  if (t.pending & REF_MULTI) {  // prim_count != 1 (external BVHs): rare
+    visit_leaf<COUNT>(S, t.pending, t.o, t.d, t.orr, t.c, cn);
+  } else {
+    const int k = (int)(t.pending & REF_IDX);
+    const float4* rec = S.pretri + 4 * (size_t)k;
+    const float4 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3v = rec[3];
+    tri_record_test<COUNT>(S, k, f0, f1, f2, f3v, t, cn);
+  }
+  t.pending = 0u;
+  trav_pop_until_pass(stk, t, cn, COUNT);
+}
+
+// lanes at an inner node (cur < T_POP, no pending leaf): one reference visit of its near child, far child pushed
+template <bool COUNT>
+DEV void trav_inner_phase(const DevScene& S, int stack_size, int* __restrict__ stk, Trav& t, Counters& cn) {
+  const float4* rec = S.pairs + 4 * (size_t)t.cur;
+  const float4 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3v = rec[3];
+  float tsL, tbL, tsR, tbR;
+  slab(f0, f1, t.o, t.inv, tsL, tbL);
+  slab(f2, f3v, t.o, t.inv, tsR, tbR);
+  const int axis = __float_as_int(f2.w);
+  const bool neg = ((t.negmask >> axis) & 1u) != 0u;
+  const uint32_t refL = __float_as_uint(f0.w), refR = __float_as_uint(f1.w);
+  const uint32_t nearRef = neg ? refR : refL;
+  uint32_t farRef = neg ? refL : refR;
+  const float tsN = neg ? tsR : tsL, tbN = neg ? tbR : tbL;
+  const float tsF = neg ? tsL : tsR, tbF = neg ? tbL : tbR;
+  const bool fB = tbF > tsF;
+  const bool fA = fB || (tbF != tbF);
+  farRef |= (fA ? REF_A : 0u) | (fB ? REF_B : 0u);
+  stk[(2 * t.sp) * 64] = (int)farRef;
+  stk[(2 * t.sp + 1) * 64] = __float_as_int(tsF);
+  t.sp++;
+  if (t.sp >= stack_size) {  // Q7
+    t.cur = T_DONE;
+    return;
+  }
+  if (COUNT) cn.node_visits++;
+  t.cur = T_POP;
+  if (ptm_min(t.c.t, tbN) > tsN) {
+    if (nearRef & REF_LEAF) t.pending = nearRef;
+    else t.cur = nearRef;
+  }
+  trav_pop_until_pass(stk, t, cn, COUNT);
 }
 
 // ---- HitRecord reconstruction (the accepting branch of the winning primitive test) ------------------

@@ -118,6 +118,8 @@ __global__ __launch_bounds__(kBlock) void k_prims(DevScene S, Paths P, const Ste
 
 // A wave refills its idle lanes once this many lanes are idle (or all are).
 constexpr int kRefillThreshold = 16;
+// The triangle phase of the flat traversal runs once this many lanes hold a pending leaf (or nothing else can run).
+constexpr int kLeafBatch = 16;
 constexpr uint32_t kBvhRange = 2048;  // slots a wave claims per global atomic (less when the queue is short)
 
 // hitScene, part 2 (hitRay.wgsl:42-110): BVH traversal by persistent, barrier-free waves.
@@ -131,7 +133,7 @@ constexpr uint32_t kBvhRange = 2048;  // slots a wave claims per global atomic (
 //   FLAT = false while-while: inner steps and triangle tests in separate loops (kept for A/B runs).
 template <bool COUNT, bool FLAT>
 __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, StepCtl* __restrict__ ctl, int stack_size,
-                                                                                       int stack_alloc, int refill_threshold,
+                                                                                       int stack_alloc, int refill_threshold, int leaf_batch,
                                                                                        unsigned long long* __restrict__ totals) {
   extern __shared__ int lds_stack[];
   const int lane = lane_id();
@@ -224,7 +226,13 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
     int working;
     if (FLAT) {
       do {
-        if (has && !(t.cur == T_DONE && t.pending == 0u)) trav_flat_iter<COUNT>(S, stack_size, stk, t, cn);
+        // triangle phase only when a batch of lanes waits for it, or nothing else can run
+        const uint64_t pm = __ballot(has && t.pending != 0u);
+        const uint64_t im = __ballot(has && t.pending == 0u && t.cur < T_POP);
+        if (pm && (__popcll(pm) >= leaf_batch || im == 0ull)) {
+          if (has && t.pending != 0u) trav_leaf_phase<COUNT>(S, stk, t, cn);
+        }
+        if (has && t.pending == 0u && t.cur < T_POP) trav_inner_phase<COUNT>(S, stack_size, stk, t, cn);
         working = __popcll(__ballot(has && !(t.cur == T_DONE && t.pending == 0u)));
       } while (working >= min_working);
     } else {
