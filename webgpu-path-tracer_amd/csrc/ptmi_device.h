@@ -484,7 +484,8 @@ DEV void trav_pop_until_pass(int* __restrict__ stk, Trav& t, Counters& cn, bool 
     const float ts = __int_as_float(stk[(2 * t.sp + 1) * 64]);
     if (count) cn.node_visits++;
     const float ct = t.c.t;
-    const bool pass = (ct != ct) ? ((e & REF_B) != 0u) : (((e & REF_A) != 0u) && (ct > ts));
+    // isnan(ct) ? B : (A && ct > ts), written without a branch: ct > ts is false for a NaN ct
+    const bool pass = (((e & REF_A) != 0u) & (ct > ts)) | ((ct != ct) & ((e & REF_B) != 0u));
     if (pass) {
       if (e & REF_LEAF) t.pending = e;
       else t.cur = e & REF_IDX;
