@@ -407,11 +407,6 @@ Paths paths_of(ptmi_ctx* c, int step, bool with_pixsum) {
 
 int stack_alloc_for(const ptmi_ctx* c) { return std::max(1, std::min(c->prm.stack_size, std::max(c->bvh_depth, 1))); }
 
-uint32_t chunk_grid(const ptmi_ctx* c, uint32_t max_items, int blocks_per_cu) {
-  uint32_t chunks = (max_items + 255) / 256;  // the kernels shrink chunks to 256 entries for small queues
-  return std::max<uint32_t>(1, std::min<uint32_t>(chunks, (uint32_t)c->num_cus * (uint32_t)blocks_per_cu));
-}
-
 // Traversal variant.  Measured on MI355X (round 1): the flat variant (one 64-byte record fetch per lane per iteration)
 // beats while-while both on a cache-resident BVH (configs[1]: 8.95 vs 8.05 Grays/s) and on a 112 MB one
 // (configs[2]: 3.48 vs ~1.6 Grays/s), so it is the default; PTMI_TRAVERSAL=1 selects while-while for A/B runs.

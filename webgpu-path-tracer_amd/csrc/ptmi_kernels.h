@@ -1,14 +1,14 @@
 // ptmi_kernels.h — the wavefront integrator's kernels (gfx950).
 //
-//   k_generate   one thread per (frame slot, owned pixel): seeds the RNG (main.wgsl:16), builds the
-//                camera ray (shootRay.wgsl), fills step 0's ray queue.
-//   k_prims      hitScene part 1 (hitRay.wgsl:6-54): spheres, quads, root-box test for every queued ray — coherent;
-//                rays that enter the root box go to the step's BVH list.
-//   k_bvh        hitScene part 2 (hitRay.wgsl:42-110): persistent single-wave blocks, one ray per lane, LDS
-//                traversal stacks, ballot-based lane refill from the BVH list; no barriers, tails only at the end.
-//   k_shade      per 2048-path chunk: LDS counting sort by material class (bin-uniform waves), then ray_color's
-//                loop body (traceRay.wgsl:10-80) + material_scatter + Russian roulette; survivors are compacted
-//                in LDS into the next step's ray queue, finished samples fold into the pixel colour.
+//   k_generate   one thread per (frame slot, owned pixel): seeds the RNG (main.wgsl:16), builds the camera ray
+//                (shootRay.wgsl), fills step 0's queue (slot = path id).
+//   k_prims      hitScene part 1 (hitRay.wgsl:6-54): spheres, quads, root-box test for every queue slot — element-wise,
+//                streaming; flags the rays that enter the root box.
+//   k_bvh        hitScene part 2 (hitRay.wgsl:42-110): persistent single-wave blocks, one ray per lane, LDS traversal
+//                stacks, ballot-based lane refill by scanning the flags; no barriers, tails only at kernel end.
+//   k_shade      per 512-slot chunk: LDS counting sort by material class (bin-uniform waves), ray_color's loop body
+//                (traceRay.wgsl:10-80) + material_scatter + Russian roulette; the survivors' next state is staged in
+//                LDS and written densely into the next step's queue (path state is compacted every step).
 //   k_accumulate framebuffer read-modify-write of main.wgsl:22-27 for every frame slot, in frame order.
 #pragma once
 #include "ptmi_device.h"
@@ -37,8 +37,6 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderConst rc, Paths P, St
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) ctl[0].n_rays = total;
 }
-
-constexpr int kChunk = 2048;
 
 // 96 VGPRs (5 waves/SIMD, no spills) measured 27 % faster than the compiler's default 106 VGPRs / 4 waves: the kernel
 // is latency bound; 6 and 8 waves/SIMD spill and lose again.
