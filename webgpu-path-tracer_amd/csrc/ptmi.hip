@@ -502,6 +502,14 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
     hipLaunchKernelGGL(k_generate, dim3(ew_grid), dim3(kBlock), 0, c->stream, rc, paths_of(c, 0, rc.num_samples > 1), ctl);
   }
   for (int s = 0; s < n_steps; s++) {
+    // With the reference's MAX_BOUNCES = 100 nearly all steps run on an empty queue (Russian roulette ends paths after
+    // a dozen bounces): from step 12 on, look at the queue length every 8 steps and stop enqueuing once it is empty.
+    if (s >= 12 && (s & 7) == 4) {
+      uint32_t left = 1;
+      HIP_TRY(c, hipMemcpyAsync(&left, &ctl[s].n_rays, sizeof left, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      if (left == 0) break;
+    }
     Paths P = paths_of(c, s, rc.num_samples > 1);
     {
       int lr = launch_intersect(c, P, ctl + s, bound);
