@@ -174,6 +174,12 @@ int ptmi_math_eval(ptmi_ctx* ctx, int fn, size_t n, const float* x, const float*
 int ptmi_build_bvh(size_t n_prims, const double* bmin, const double* bmax, int prim_type, float* nodes_out,
                    int64_t* order_out);
 
+/* OBJ text -> de-indexed vertex / normal arrays with the reference's accepted grammar and quirks
+ * (lib/primitives/objReader.js:10-68: `v`, `vn`, `f a/b/c` triangles; tokens go through JS Number()).  The arrays are
+ * malloc'ed; release them with ptmi_free.  Counts are in floats. */
+int ptmi_obj_parse(const char* text, size_t len, float** vertices_out, size_t* n_vertices, float** normals_out, size_t* n_normals);
+void ptmi_free(void* p);
+
 #ifdef __cplusplus
 }
 #endif

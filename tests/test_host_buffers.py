@@ -134,3 +134,35 @@ def test_interior_and_buddha_class_generators(pkg):
         assert np.abs(nn - 1).max() < 1e-5
         assert np.isfinite(m["vertices"]).all() and np.abs(m["vertices"]).max() <= 1.0 + 1e-6
         assert np.array_equal(m["vertices"], fn(n)["vertices"])
+
+
+WEIRD_OBJ = "# c\nv  1 2 3\nv 1e2 -.5 +3.\nv 0x10 Infinity abc\nvn 0 0 1\n\tvn 1 0 0  \r\nf 1/1/1 2/2/2 3/3/1\nf 1//2 9/9/9 0/0/0\nf 3/1/2 2/1/1 1/1/1 extra\nvt 0 0\ng grp\n"
+
+
+def test_obj_grammar_quirks_python_vs_native(pkg):
+    """lib/primitives/objReader.js:10-68: tokens go through Number() ('' -> 0, junk -> NaN), only `v`, `vn`, `f` lines
+    count, an out-of-range index yields NaN.  The native parser and the Python mirror agree bit for bit."""
+    from webgpu_path_tracer_amd.host import ObjReader
+
+    a, b = ObjReader.parse(WEIRD_OBJ), pkg.ptmi.NativeHost().parse_obj(WEIRD_OBJ)
+    for k in ("vertices", "normals"):
+        assert a[k].size == b[k].size and np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    v = a["vertices"]
+    assert list(v[:4]) == [0.0, 1.0, 2.0, 3.0]          # "v  1 2 3": the double space makes an empty token -> 0
+    assert v[7] == 16.0 and np.isinf(v[8]) and np.isnan(v[9])  # 0x10, Infinity, abc
+    assert np.isnan(v).sum() >= 3                        # index 9 and 0 do not exist
+
+
+@needs_assets
+def test_native_obj_parser_matches_python_on_reference_meshes(pkg):
+    import glob
+
+    from webgpu_path_tracer_amd.host import ObjReader
+
+    nat = pkg.ptmi.NativeHost()
+    files = sorted(glob.glob(ASSETS + "/*.obj"))
+    assert len(files) >= 8
+    for f in files:
+        a, b = ObjReader.load_model(f), nat.load_obj(f)
+        for k in ("vertices", "normals"):
+            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), (f, k)

@@ -6,8 +6,11 @@
 // to f32 on the final store like `new Float32Array(...)` (lib/scene.js:304).  Output is byte-identical
 // to the reference's for the same boxes (tests/test_host_buffers.py checks it against goldens).
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../include/ptmi.h"
@@ -100,6 +103,145 @@ extern "C" int ptmi_build_bvh(size_t n_prims, const double* bmin, const double* 
       st.emplace_back(b.right[n], nxt);
       st.emplace_back(b.left[n], b.right[n]);
     }
+  }
+  return PTMI_OK;
+}
+
+
+// ---- OBJ parsing with the reference's grammar (lib/primitives/objReader.js:10-68) ---------------------------------
+namespace {
+
+bool js_space(unsigned char ch) { return ch == ' ' || ch == '\t' || ch == '\r' || ch == '\n' || ch == '\v' || ch == '\f'; }
+
+// JavaScript Number(token) for the tokens an OBJ line can produce: "" -> 0, decimal literals with optional sign /
+// fraction / exponent, [+-]Infinity, 0x / 0o / 0b integers; anything else -> NaN.
+double js_number(const char* b, const char* e) {
+  while (b < e && js_space((unsigned char)*b)) b++;
+  while (e > b && js_space((unsigned char)e[-1])) e--;
+  if (b == e) return 0.0;
+  std::string t(b, e);
+  const char* p = t.c_str();
+  bool neg = false;
+  if (t.size() > 2 && p[0] == '0' && (p[1] == 'x' || p[1] == 'X' || p[1] == 'o' || p[1] == 'O' || p[1] == 'b' || p[1] == 'B')) {
+    int base = (p[1] == 'x' || p[1] == 'X') ? 16 : (p[1] == 'o' || p[1] == 'O') ? 8 : 2;
+    char* end = nullptr;
+    unsigned long long v = strtoull(p + 2, &end, base);
+    return (*end == 0) ? (double)v : NAN;
+  }
+  const char* q = p;
+  if (*q == '+' || *q == '-') neg = (*q == '-'), q++;
+  if (strcmp(q, "Infinity") == 0) return neg ? -INFINITY : INFINITY;
+  // strict decimal: digits [. digits] [e[+-]digits], at least one digit in the mantissa
+  const char* r = q;
+  int digits = 0;
+  while (*r >= '0' && *r <= '9') r++, digits++;
+  if (*r == '.') {
+    r++;
+    while (*r >= '0' && *r <= '9') r++, digits++;
+  }
+  if (digits == 0) return NAN;
+  if (*r == 'e' || *r == 'E') {
+    const char* x = r + 1;
+    if (*x == '+' || *x == '-') x++;
+    if (!(*x >= '0' && *x <= '9')) return NAN;
+    while (*x >= '0' && *x <= '9') x++;
+    r = x;
+  }
+  if (*r != 0) return NAN;
+  return strtod(p, nullptr);
+}
+
+struct ObjRows {
+  std::vector<double> data;      // all numbers of all rows, concatenated
+  std::vector<uint32_t> offset;  // row i = data[offset[i] .. offset[i+1])
+  ObjRows() { offset.push_back(0); }
+  void add_row_split_on_space(const char* b, const char* e) {  // line.split(" ").slice(1).map(Number)
+    const char* p = b;
+    bool first = true;
+    while (true) {
+      const char* q = p;
+      while (q < e && *q != ' ') q++;
+      if (!first) data.push_back(js_number(p, q));
+      first = false;
+      if (q >= e) break;
+      p = q + 1;
+    }
+    offset.push_back((uint32_t)data.size());
+  }
+  size_t rows() const { return offset.size() - 1; }
+};
+
+}  // namespace
+
+extern "C" void ptmi_free(void* p) { free(p); }
+
+extern "C" int ptmi_obj_parse(const char* text, size_t len, float** vertices_out, size_t* n_vertices, float** normals_out, size_t* n_normals) {
+  if (!text || !vertices_out || !n_vertices || !normals_out || !n_normals) return PTMI_ERR_INVALID_ARG;
+  *vertices_out = *normals_out = nullptr;
+  *n_vertices = *n_normals = 0;
+  ObjRows V, N;
+  std::vector<double> vidx, nidx;  // doubles: an index token may be NaN
+  try {
+    const char* p = text;
+    const char* end = text + len;
+    while (p <= end) {
+      const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+      const char* le = nl ? nl : end;
+      const char *b = p, *e = le;  // line.trim()
+      while (b < e && js_space((unsigned char)*b)) b++;
+      while (e > b && js_space((unsigned char)e[-1])) e--;
+      if (b < e && *b != '#') {
+        if (e - b >= 2 && b[0] == 'v' && b[1] == ' ') {
+          V.add_row_split_on_space(b, e);
+        } else if (e - b >= 2 && b[0] == 'f' && b[1] == ' ') {  // split(/[\s/]+/).slice(1); i % 3 == 0 -> vertex, == 2 -> normal
+          const char* q = b;
+          int tok = -1;  // token 0 is "f"
+          while (q < e) {
+            const char* t0 = q;
+            while (q < e && !js_space((unsigned char)*q) && *q != '/') q++;
+            if (tok >= 0) {
+              if (tok % 3 == 0) vidx.push_back(js_number(t0, q) - 1);
+              else if (tok % 3 == 2) nidx.push_back(js_number(t0, q) - 1);
+            }
+            tok++;
+            while (q < e && (js_space((unsigned char)*q) || *q == '/')) q++;
+          }
+        } else if (e - b >= 3 && b[0] == 'v' && b[1] == 'n' && b[2] == ' ') {
+          N.add_row_split_on_space(b, e);
+        }
+      }
+      if (!nl) break;
+      p = nl + 1;
+    }
+    auto flatten = [](const ObjRows& R, const std::vector<double>& idx, float** out, size_t* n) -> int {
+      std::vector<float> flat;
+      flat.reserve(idx.size() * 3);
+      for (double d : idx) {
+        // array[v] with v not a valid index is `undefined`; .flat(1) keeps it as one element -> NaN in the Float32Array
+        if (!(d >= 0) || d != std::floor(d) || d >= (double)R.rows()) {
+          flat.push_back(NAN);
+          continue;
+        }
+        size_t r = (size_t)d;
+        for (uint32_t k = R.offset[r]; k < R.offset[r + 1]; k++) flat.push_back((float)R.data[k]);
+      }
+      *n = flat.size();
+      if (flat.empty()) return PTMI_OK;
+      *out = (float*)malloc(flat.size() * sizeof(float));
+      if (!*out) return PTMI_ERR_NO_MEMORY;
+      memcpy(*out, flat.data(), flat.size() * sizeof(float));
+      return PTMI_OK;
+    };
+    int rc = flatten(V, vidx, vertices_out, n_vertices);
+    if (rc) return rc;
+    rc = flatten(N, nidx, normals_out, n_normals);
+    if (rc) {
+      free(*vertices_out);
+      *vertices_out = nullptr;
+      return rc;
+    }
+  } catch (...) {
+    return PTMI_ERR_NO_MEMORY;
   }
   return PTMI_OK;
 }

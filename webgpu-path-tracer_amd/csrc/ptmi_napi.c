@@ -43,6 +43,8 @@ FN(ptmi_set_timing)
 FN(ptmi_get_stats)
 FN(ptmi_reset_stats)
 FN(ptmi_build_bvh)
+FN(ptmi_obj_parse)
+FN(ptmi_free)
 
 static int load_lib(char* err, size_t errlen) {
   if (g_lib) return 0;
@@ -76,6 +78,7 @@ static int load_lib(char* err, size_t errlen) {
   LOAD(ptmi_get_params) LOAD(ptmi_upload) LOAD(ptmi_resize) LOAD(ptmi_clear_framebuffer) LOAD(ptmi_set_shard) LOAD(ptmi_render_frame)
   LOAD(ptmi_render) LOAD(ptmi_synchronize) LOAD(ptmi_read_framebuffer) LOAD(ptmi_write_framebuffer) LOAD(ptmi_resolve_rgba8)
   LOAD(ptmi_set_counters) LOAD(ptmi_set_timing) LOAD(ptmi_get_stats) LOAD(ptmi_reset_stats) LOAD(ptmi_build_bvh)
+  LOAD(ptmi_obj_parse) LOAD(ptmi_free)
   return 0;
 }
 
@@ -493,6 +496,59 @@ static napi_value js_build_bvh(napi_env env, napi_callback_info info) {
   return out;
 }
 
+/* parseObj(text: string | Uint8Array) -> { vertices: Float32Array, normals: Float32Array }  (objReader.js grammar) */
+static napi_value js_parse_obj(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (get_args(env, info, 1, a)) return NULL;
+  char* text = NULL;
+  size_t len = 0;
+  int owned = 0;
+  napi_valuetype ty;
+  CHECK_NAPI(napi_typeof(env, a[0], &ty));
+  if (ty == napi_string) {
+    CHECK_NAPI(napi_get_value_string_utf8(env, a[0], NULL, 0, &len));
+    text = (char*)malloc(len + 1);
+    if (!text) {
+      napi_throw_error(env, NULL, "parseObj: out of memory");
+      return NULL;
+    }
+    owned = 1;
+    if (napi_get_value_string_utf8(env, a[0], text, len + 1, &len) != napi_ok) {
+      free(text);
+      napi_throw_error(env, NULL, "parseObj: cannot read string");
+      return NULL;
+    }
+  } else {
+    void* data;
+    if (typed(env, a[0], napi_uint8_array, "parseObj(text)", &data, &len)) return NULL;
+    text = (char*)data;
+  }
+  float *v = NULL, *n = NULL;
+  size_t nv = 0, nn = 0;
+  int st = p_ptmi_obj_parse(text, len, &v, &nv, &n, &nn);
+  if (owned) free(text);
+  if (st) return throw_status(env, NULL, st, "ptmi_obj_parse");
+  napi_value abv, abn, tv, tn, out;
+  void *pv = NULL, *pn = NULL;
+  napi_status s1 = napi_create_arraybuffer(env, nv * 4, &pv, &abv), s2 = napi_create_arraybuffer(env, nn * 4, &pn, &abn);
+  if (s1 == napi_ok && s2 == napi_ok) {
+    if (nv) memcpy(pv, v, nv * 4);
+    if (nn) memcpy(pn, n, nn * 4);
+  }
+  p_ptmi_free(v);
+  p_ptmi_free(n);
+  if (s1 != napi_ok || s2 != napi_ok) {
+    napi_throw_error(env, NULL, "parseObj: cannot allocate result");
+    return NULL;
+  }
+  CHECK_NAPI(napi_create_typedarray(env, napi_float32_array, nv, abv, 0, &tv));
+  CHECK_NAPI(napi_create_typedarray(env, napi_float32_array, nn, abn, 0, &tn));
+  CHECK_NAPI(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "vertices", tv);
+  napi_set_named_property(env, out, "normals", tn);
+  return out;
+}
+
 static napi_value init(napi_env env, napi_value exports) {
   char err[4400];
   if (load_lib(err, sizeof err)) {
@@ -507,7 +563,7 @@ static napi_value init(napi_env env, napi_value exports) {
       {"upload", js_upload}, {"resize", js_resize}, {"clear", js_clear}, {"setShard", js_set_shard}, {"renderFrame", js_render_frame},
       {"render", js_render}, {"synchronize", js_synchronize}, {"readFramebuffer", js_read_fb}, {"writeFramebuffer", js_write_fb},
       {"resolveRGBA8", js_resolve}, {"setCounters", js_set_counters}, {"setTiming", js_set_timing}, {"stats", js_stats},
-      {"resetStats", js_reset_stats}, {"buildBVH", js_build_bvh},
+      {"resetStats", js_reset_stats}, {"buildBVH", js_build_bvh}, {"parseObj", js_parse_obj},
   };
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
     napi_value f;

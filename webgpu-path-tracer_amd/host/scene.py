@@ -127,14 +127,29 @@ class Mesh:
 
 
 # ----------------------------------------------------------------------------- lib/primitives/objReader.js
+_DEC = None
+
+
 def _js_number(tok):
-    tok = tok.strip()
+    """JavaScript Number(token): '' -> 0, decimal literal, [+-]Infinity, 0x/0o/0b integer; anything else NaN."""
+    global _DEC
+    import re
+
+    if _DEC is None:
+        _DEC = re.compile(r"[+-]?(\d+\.?\d*|\.\d+)([eE][+-]?\d+)?\Z")
+    tok = tok.strip(" \t\r\n\v\f")
     if tok == "":
         return 0.0
-    try:
-        return float(tok)
-    except ValueError:
-        return float("nan")
+    if len(tok) > 2 and tok[0] == "0" and tok[1] in "xXoObB":
+        try:
+            return float(int(tok[2:], {"x": 16, "o": 8, "b": 2}[tok[1].lower()]))
+        except ValueError:
+            return float("nan")
+    if tok in ("Infinity", "+Infinity"):
+        return float("inf")
+    if tok == "-Infinity":
+        return float("-inf")
+    return float(tok) if _DEC.match(tok) else float("nan")
 
 
 class ObjReader:
@@ -151,13 +166,21 @@ class ObjReader:
                 verts.append([_js_number(t) for t in line.split(" ")[1:]])
             elif line.startswith("f "):
                 toks = re.split(r"[\s/]+", line)[1:]
-                vidx.extend(int(_js_number(t)) - 1 for i, t in enumerate(toks) if i % 3 == 0)
-                nidx.extend(int(_js_number(t)) - 1 for i, t in enumerate(toks) if i % 3 == 2)
+                vidx.extend(_js_number(t) - 1 for i, t in enumerate(toks) if i % 3 == 0)
+                nidx.extend(_js_number(t) - 1 for i, t in enumerate(toks) if i % 3 == 2)
             elif line.startswith("vn "):
                 norms.append([_js_number(t) for t in line.split(" ")[1:]])
-        V = [c for i in vidx for c in verts[i]]
-        N = [c for i in nidx for c in norms[i]]
-        return {"vertices": np.asarray(V, np.float64).astype(np.float32), "normals": np.asarray(N, np.float64).astype(np.float32)}
+
+        def flat(rows, idx):  # indexArray.map(v => rows[v]).flat(1): an invalid index is `undefined` -> NaN
+            out = []
+            for d in idx:
+                if d != d or d < 0 or d != int(d) or d >= len(rows):
+                    out.append(float("nan"))
+                else:
+                    out.extend(rows[int(d)])
+            return np.asarray(out, np.float64).astype(np.float32)
+
+        return {"vertices": flat(verts, vidx), "normals": flat(norms, nidx)}
 
     @staticmethod
     def load_model(path):

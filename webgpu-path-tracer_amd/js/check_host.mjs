@@ -26,6 +26,13 @@ async function check(tag, make) {
     await check('c2', () => c2Scene(obj('monkey_968.obj')));
     await check('c2m', () => c2mScene(obj('icosphere.obj'), obj('cube.obj')));
   }
+  if (assets && fs.existsSync(path.join(assets, 'monkey_968.obj'))) {
+    for (const f of ['cube.obj', 'monkey_968.obj', 'hole.obj']) {
+      const text = fs.readFileSync(path.join(assets, f), 'utf8');
+      const a = ObjReader.parse(text), b = loadNative().parseObj(text);
+      report[`objparse.${f}`] = same(a.vertices, new Uint8Array(b.vertices.buffer)) && same(a.normals, new Uint8Array(b.normals.buffer));
+    }
+  }
   const man = JSON.parse(fs.readFileSync(path.join(golden, 'manifest.json'), 'utf8'));
   for (const [k, [eye, center]] of Object.entries(CAMERAS)) {
     const c = new Camera(); c.set_camera(eye, center, [0, 1, 0]);

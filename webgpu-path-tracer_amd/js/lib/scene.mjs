@@ -102,14 +102,15 @@ export class ObjReader {   // lib/primitives/objReader.js:10-68
         normalIndex.push(...temp.filter((v, k) => k % 3 == 2).map(Number).map((v) => v - 1));
       } else if (line.startsWith('vn ')) normalArray.push(line.split(' ').slice(1).map(Number));
     }
-    const N = [], V = [];
-    for (const k of normalIndex) N.push(...normalArray[k]);
-    for (const k of indexArray) V.push(...vertexArray[k]);
+    const N = normalIndex.map((k) => normalArray[k]).flat(1);   // an invalid index stays `undefined` -> NaN
+    const V = indexArray.map((k) => vertexArray[k]).flat(1);
     return { vertices: new Float32Array(V), normals: new Float32Array(N) };
   }
-  static async load_model(path) {
+  // `native` = the addon (ptmi.node): same result from the C++ parser of libptmi.so, much faster on large files
+  static async load_model(path, native = null) {
     const file = await fetch(path);
-    return ObjReader.parse(await file.text());
+    const text = await file.text();
+    return native ? native.parseObj(text) : ObjReader.parse(text);
   }
 }
 

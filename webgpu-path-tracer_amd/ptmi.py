@@ -18,6 +18,7 @@ SYMBOLS = [
     "ptmi_render_frame", "ptmi_render", "ptmi_synchronize", "ptmi_read_framebuffer", "ptmi_write_framebuffer",
     "ptmi_framebuffer_device_ptr", "ptmi_bind_framebuffer", "ptmi_stream", "ptmi_resolve_rgba8", "ptmi_set_counters",
     "ptmi_set_timing", "ptmi_get_stats", "ptmi_reset_stats", "ptmi_trace", "ptmi_math_eval", "ptmi_build_bvh",
+    "ptmi_obj_parse", "ptmi_free",
 ]
 
 
@@ -98,6 +99,9 @@ def load_library(build=False):
     L.ptmi_trace.argtypes = [vp, sz, fp, fp, fp]
     L.ptmi_math_eval.argtypes = [vp, i32, sz, fp, fp, fp]
     L.ptmi_build_bvh.argtypes = [sz, fp, fp, i32, fp, fp]
+    L.ptmi_obj_parse.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(vp), ctypes.POINTER(sz)]
+    L.ptmi_free.argtypes = [vp]
+    L.ptmi_free.restype = None
     _lib = L
     return L
 
@@ -133,6 +137,26 @@ class NativeHost:
         if st != 0:
             raise PtmiError(st, "ptmi_build_bvh failed")
         return nodes, order
+
+
+    def parse_obj(self, text):
+        """ObjReader.parse in native code: {vertices, normals} float32 arrays (lib/primitives/objReader.js grammar)."""
+        data = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+        pv, pn, nv, nn = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_size_t()
+        st = self.lib.ptmi_obj_parse(data, len(data), ctypes.byref(pv), ctypes.byref(nv), ctypes.byref(pn), ctypes.byref(nn))
+        if st != 0:
+            raise PtmiError(st, "ptmi_obj_parse failed")
+        try:
+            v = np.ctypeslib.as_array(ctypes.cast(pv, ctypes.POINTER(ctypes.c_float)), (nv.value,)).copy() if nv.value else np.zeros(0, np.float32)
+            n = np.ctypeslib.as_array(ctypes.cast(pn, ctypes.POINTER(ctypes.c_float)), (nn.value,)).copy() if nn.value else np.zeros(0, np.float32)
+        finally:
+            self.lib.ptmi_free(pv)
+            self.lib.ptmi_free(pn)
+        return {"vertices": v, "normals": n}
+
+    def load_obj(self, path):
+        with open(path, "rb") as f:
+            return self.parse_obj(f.read())
 
 
 class Context:
