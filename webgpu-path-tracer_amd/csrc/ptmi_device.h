@@ -196,6 +196,22 @@ DEV void camera_ray(const RenderConst& rc, uint32_t pix, int k, uint32_t& rng, f
           ((m[2] * 0.0f + m[6] * 0.0f) + m[10] * 0.0f) + m[14] * 1.0f);
 }
 
+// Loads whose address is the same for every lane of a wave (primitive tables walked by a wave-uniform loop index):
+// read through the constant address space, so that the compiler emits scalar loads (s_load, SGPR results, several
+// in flight, no VMEM round trip per access).  Legal because no kernel ever writes the scene tables.
+#define PTMI_CONST_AS __attribute__((address_space(4)))
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+DEV float4 ldu(const float4* p) {  // (HIP's float4 is a class: its copy would fall back to a generic-pointer load)
+  const v4f_t v = *(const PTMI_CONST_AS v4f_t*)(p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+DEV int2 ldu(const int2* p) {
+  const v2i_t v = *(const PTMI_CONST_AS v2i_t*)(p);
+  return make_int2(v.x, v.y);
+}
+DEV int ldu(const int* p) { return *(const PTMI_CONST_AS int*)(p); }
+
 // ---- closest-hit record carried in registers during hitScene ----------------------------------------
 struct Closest {
   float t;        // closest_so_far
@@ -230,8 +246,8 @@ DEV bool sphere_root(f3 center, float r, float tmin, float tmax, f3 o, f3 d, flo
 template <bool COUNT>
 DEV void hit_spheres(const DevScene& S, f3 o, f3 d, uint32_t& rng, Closest& c, Counters& cn) {
   for (int i = 0; i < S.n_spheres; i++) {
-    float4 s0 = S.spheres[2 * i];
-    int2 info = S.sphere_info[i];
+    float4 s0 = ldu(S.spheres + 2 * i);
+    int2 info = ldu(S.sphere_info + i);
     f3 center = mk3(s0);
     float r = s0.w;
     if (COUNT) cn.sphere_tests++;
@@ -253,7 +269,7 @@ DEV void hit_spheres(const DevScene& S, f3 o, f3 d, uint32_t& rng, Closest& c, C
       if (rec1 < 0) rec1 = 0;
       c.mat = info.x;  // hitRec.material written before the final accept/reject (Q3)
       if (COUNT) cn.mat_fetches++;
-      float roughness = S.mats[4 * info.x + 3].x;
+      float roughness = ldu(S.mats + 4 * info.x + 3).x;
       float ray_length = len3(d);
       float dist_inside = (rec2 - rec1) * ray_length;
       float hit_dist = roughness * ptm_log(rand2D(rng));
@@ -269,7 +285,9 @@ template <bool COUNT>
 DEV void hit_quads(const DevScene& S, f3 o, f3 d, Closest& c, Counters& cn) {
   for (int i = 0; i < S.n_quads; i++) {
     const float4* q = S.quads + 5 * i;
-    float4 q3 = q[3];
+    // the whole 80-byte record and the material id at once: scalar loads, one wait
+    const float4 q0 = ldu(q), q1 = ldu(q + 1), q2 = ldu(q + 2), q3 = ldu(q + 3), q4 = ldu(q + 4);
+    const int qmat = ldu(S.quad_mat + i);
     f3 n = mk3(q3);
     if (COUNT) cn.quad_tests++;
     if (dot3(d, n) > 0) continue;
@@ -278,14 +296,14 @@ DEV void hit_quads(const DevScene& S, f3 o, f3 d, Closest& c, Counters& cn) {
     float t = (q3.w - dot3(n, o)) / denom;
     if (t <= kTmin || t >= c.t) continue;
     f3 isect = o + t * d;
-    f3 ph = isect - mk3(q[0]);
-    f3 w = mk3(q[4]);
-    float alpha = dot3(w, cross3(ph, mk3(q[2])));
-    float beta = dot3(w, cross3(mk3(q[1]), ph));
+    f3 ph = isect - mk3(q0);
+    f3 w = mk3(q4);
+    float alpha = dot3(w, cross3(ph, mk3(q2)));
+    float beta = dot3(w, cross3(mk3(q1), ph));
     if (alpha < 0 || 1 < alpha || beta < 0 || 1 < beta) continue;
     c.t = t;
     c.prim = (K_QUAD << 28) | (uint32_t)i;
-    c.mat = S.quad_mat[i];
+    c.mat = qmat;
     if (COUNT) cn.mat_fetches++;
   }
 }
