@@ -1,0 +1,9 @@
+#!/bin/bash
+# usage: tools/quick_bench.sh "c2 c3:128 c4:64" -- short bench lines for A/B runs (workload[:spp])
+for item in $1; do
+  w=${item%%:*}; spp=""; [[ "$item" == *:* ]] && spp="--spp ${item##*:}"
+  timeout -k 10 300 python bench.py --workload $w --steps ${STEPS:-2} --warmup 1 --cpu-seconds 0 $spp 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('$w:', round(d['value']), 'Mrays/s', round(d['ms_per_step'],1), 'ms', {k: round(v,1) for k,v in d['roofline']['kernel_ms_one_step_counted_pass'].items()})"
+done

@@ -63,6 +63,7 @@ struct ptmi_ctx {
   DevScene S{};
   int bvh_depth = 0;             // max number of inner nodes on a root-to-leaf path
   bool has_unknown_material = false;
+  int material_classes = 0;      // distinct shade bins among the materials: k_shade sorts only when > 1
 
   int W = 0, H = 0;
   DBuf d_fb_own;
@@ -181,6 +182,17 @@ int prepare_scene(ptmi_ctx* c) {
     float ty = c->h_mats[16 * (size_t)i + 14];
     if (!(ty == 0.0f || ty == 1.0f || ty == 2.0f || ty == 3.0f)) c->has_unknown_material = true;
   }
+  // material word = id | shade bin << 28 (ptmi_device.h)
+  std::vector<int32_t> mat_word((size_t)n_mat);
+  uint32_t classes = 0;
+  for (int i = 0; i < n_mat; i++) {
+    float ty = c->h_mats[16 * (size_t)i + 14];
+    int bin = (ty == 0.0f) ? BIN_LAMBERTIAN : (ty == 1.0f) ? BIN_MIRROR : (ty == 2.0f) ? BIN_GLASS : (ty == 3.0f) ? BIN_ISOTROPIC : BIN_OTHER;
+    mat_word[i] = i | (bin << HITMAT_BIN_SHIFT);
+    classes |= 1u << bin;
+  }
+  c->material_classes = __builtin_popcount(classes);
+  if (n_mat >= (1 << HITMAT_BIN_SHIFT)) return fail(c, PTMI_ERR_UNSUPPORTED, "more than 2^28 materials");
   std::vector<int32_t> sphere_info(2 * (size_t)n_sph), quad_mat((size_t)n_quad);
   for (int i = 0; i < n_sph; i++) {
     int m;
@@ -189,7 +201,7 @@ int prepare_scene(ptmi_ctx* c) {
       return fail(c, PTMI_ERR_BAD_SCENE, msg);
     }
     float medium = c->h_mats[16 * (size_t)m + 14];
-    sphere_info[2 * (size_t)i] = m;
+    sphere_info[2 * (size_t)i] = mat_word[m];
     sphere_info[2 * (size_t)i + 1] = (medium < 3.0f) ? 0 : 1;  // hitRay.wgsl:8-9
   }
   int light = -1;
@@ -199,7 +211,7 @@ int prepare_scene(ptmi_ctx* c) {
       snprintf(msg, sizeof msg, "quad %d: material_id out of range [0,%d)", i, n_mat);
       return fail(c, PTMI_ERR_BAD_SCENE, msg);
     }
-    quad_mat[i] = m;
+    quad_mat[i] = mat_word[m];
     if (light < 0 && c->h_mats[16 * (size_t)m + 8] > 0.0f) light = i;  // common.wgsl:258-269
   }
   for (int i = 0; i < n_mesh; i++) {
@@ -223,8 +235,10 @@ int prepare_scene(ptmi_ctx* c) {
     float ACx = t[8] - t[0], ACy = t[9] - t[1], ACz = t[10] - t[2];
     o[0] = t[0], o[1] = t[1], o[2] = t[2];
     memcpy(&o[3], &mesh, 4);
-    o[4] = ABx, o[5] = ABy, o[6] = ABz, o[7] = 0.0f;
-    o[8] = ACx, o[9] = ACy, o[10] = ACz, o[11] = 0.0f;
+    o[4] = ABx, o[5] = ABy, o[6] = ABz;
+    o[8] = ACx, o[9] = ACy, o[10] = ACz;
+    memcpy(&o[7], &mat_word[c->h_meshes[4 * (size_t)mesh + 3]], 4);
+    memcpy(&o[11], &c->h_meshes[4 * (size_t)mesh + 2], 4);
     o[12] = ABy * ACz - ABz * ACy;
     o[13] = ABz * ACx - ABx * ACz;
     o[14] = ABx * ACy - ABy * ACx;
@@ -495,6 +509,10 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   const uint32_t sgrid = std::max<uint32_t>(1, std::min<uint32_t>((bound + kSChunk - 1) / kSChunk, (uint32_t)c->num_cus * 5));
   unsigned long long* tot = c->d_totals.as<unsigned long long>();
 
+  // k_shade sorts its chunks by material class only when the scene has more than one (PTMI_SORT=0/1 overrides, for A/B runs)
+  const int sort_env = env_int("PTMI_SORT", -1);
+  const bool sort = sort_env >= 0 ? sort_env != 0 : c->material_classes > 1;
+
   ScopedSpan whole(c, T_RENDER);
   {
     ScopedSpan s(c, T_OTHER);
@@ -517,8 +535,15 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
     }
     {
       ScopedSpan sp(c, T_SHADE);
-      if (p.importance_sampling) hipLaunchKernelGGL(k_shade<true>, dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, tot);
-      else hipLaunchKernelGGL(k_shade<false>, dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, tot);
+#define PTMI_LAUNCH_SHADE(IS, SO) hipLaunchKernelGGL((k_shade<IS, SO>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, tot)
+      if (p.importance_sampling) {
+        if (sort) PTMI_LAUNCH_SHADE(true, true);
+        else PTMI_LAUNCH_SHADE(true, false);
+      } else {
+        if (sort) PTMI_LAUNCH_SHADE(false, true);
+        else PTMI_LAUNCH_SHADE(false, false);
+      }
+#undef PTMI_LAUNCH_SHADE
     }
     c->stats.intersect_launches++;
     c->stats.shade_launches++;

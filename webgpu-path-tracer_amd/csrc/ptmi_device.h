@@ -85,14 +85,18 @@ DEV float rand2D(uint32_t& s) {
 //              inner : index of the child's own pair record
 //              leaf  : REF_LEAF | prim_id                      (prim_count == 1, the reference's builder)
 //                      REF_LEAF | REF_MULTI | leaf_table index (any other prim_count: {prim_id, count})
-//   pretri : {A.xyz, mesh_id} {AB.xyz,0} {AC.xyz,0} {cross(AB,AC).xyz,0}                (64 B, aligned)
+//   pretri : {A.xyz, mesh_id} {AB.xyz, material word} {AC.xyz, global_id} {cross(AB,AC).xyz,0}   (64 B, aligned)
+//            the mesh's material word and transform index ride along, so that accepting a hit or building the
+//            object-space ray needs no dependent `meshes[mesh]` fetch first.
 // Both hold values the shader would load or compute itself (common.wgsl:199-201) — same f32 operations.
+// "Material word" = material id | shade bin of that material << 28: sphere_info.x, quad_mat and pretri carry it, it
+// flows through Closest.mat into the hitmat word, and k_shade sorts on it without touching the material table.
 constexpr uint32_t REF_LEAF = 0x80000000u, REF_MULTI = 0x40000000u, REF_B = 0x20000000u, REF_A = 0x10000000u, REF_IDX = 0x0fffffffu;
 struct DevScene {
   const float4* spheres;  // 2 float4 / sphere
-  const int2* sphere_info;  // {material_id, is_volume}
+  const int2* sphere_info;  // {material word, is_volume}
   const float4* quads;  // 5 float4 / quad
-  const int* quad_mat;
+  const int* quad_mat;      // material word per quad
   const float4* tris;    // 6 float4 / triangle (raw)
   const float4* pretri;  // 4 float4 / triangle
   const int4* meshes;
@@ -113,10 +117,12 @@ struct DevScene {
 // indexed by path id = frame_slot * n_local + local pixel index: it changes rarely (emissive hits, misses) and k_accumulate needs it
 // by pixel.
 constexpr uint32_t PID_HOLE = 0xffffffffu;
-constexpr uint32_t HITMAT_MISS = 0x0fffffffu;  // hitScene returned false (so far)
-constexpr uint32_t HITMAT_HOLE = 0x0ffffffeu;  // slot holds no path
+constexpr uint32_t HITMAT_ID = 0x0fffffffu;    // bits 0..27: material id
+constexpr int HITMAT_BIN_SHIFT = 28;           // bits 28..30: shade bin (BIN_*) of that material; 7 = no path
+constexpr uint32_t HITMAT_WORD = 0x7fffffffu;  // id + bin = the "material word"
+constexpr uint32_t HITMAT_MISS = ((uint32_t)BIN_MISS << HITMAT_BIN_SHIFT) | 0x0fffffffu;  // hitScene returned false (so far)
+constexpr uint32_t HITMAT_HOLE = (7u << HITMAT_BIN_SHIFT) | 0x0ffffffeu;                   // slot holds no path
 constexpr uint32_t HITMAT_BVH = 0x80000000u;   // flag: the ray entered the root box, k_bvh still has to traverse it
-constexpr uint32_t HITMAT_ID = 0x0fffffffu;
 
 struct Slots {
   float4* o;      // {origin.xyz, -}
@@ -217,7 +223,7 @@ struct Closest {
   float t;        // closest_so_far
   float u, v;     // barycentrics of the winning triangle
   uint32_t prim;  // kind<<28 | index, K_NONE if nothing accepted yet
-  int mat;        // effective material id
+  int mat;        // effective material (material word: id | bin << 28)
 };
 
 struct Counters {
@@ -269,7 +275,7 @@ DEV void hit_spheres(const DevScene& S, f3 o, f3 d, uint32_t& rng, Closest& c, C
       if (rec1 < 0) rec1 = 0;
       c.mat = info.x;  // hitRec.material written before the final accept/reject (Q3)
       if (COUNT) cn.mat_fetches++;
-      float roughness = ldu(S.mats + 4 * info.x + 3).x;
+      float roughness = ldu(S.mats + 4 * (info.x & (int)HITMAT_ID) + 3).x;
       float ray_length = len3(d);
       float dist_inside = (rec2 - rec1) * ray_length;
       float hit_dist = roughness * ptm_log(rand2D(rng));
@@ -325,8 +331,7 @@ struct ObjRay {
   f3 o, d;
   int mesh;
 };
-DEV void obj_ray_for(const DevScene& S, int mesh, f3 o, f3 d, ObjRay& r) {
-  int gid = S.meshes[mesh].z;
+DEV void obj_ray_for(const DevScene& S, int mesh, int gid, f3 o, f3 d, ObjRay& r) {
   const float4* inv = S.xforms + 8 * gid + 4;
   float4 o4 = mat_mul(inv, o, 1.0f), d4 = mat_mul(inv, d, 0.0f);
   r.o = mk3(o4);
@@ -341,7 +346,7 @@ DEV void hit_triangle(const DevScene& S, int k, f3 o, f3 d, ObjRay& orr, Closest
   const float4* pt = S.pretri + 4 * (size_t)k;
   float4 t0 = pt[0], t1 = pt[1], t2 = pt[2], t3 = pt[3];
   int mesh = __float_as_int(t0.w);
-  if (mesh != orr.mesh) obj_ray_for(S, mesh, o, d, orr);
+  if (mesh != orr.mesh) obj_ray_for(S, mesh, __float_as_int(t2.w), o, d, orr);
   if (COUNT) cn.tri_tests++;
   f3 A = mk3(t0), AB = mk3(t1), AC = mk3(t2), N = mk3(t3);
   float det = -dot3(orr.d, N);
@@ -358,7 +363,7 @@ DEV void hit_triangle(const DevScene& S, int k, f3 o, f3 d, ObjRay& orr, Closest
   c.u = u;
   c.v = v;
   c.prim = (K_TRI << 28) | (uint32_t)k;
-  c.mat = S.meshes[mesh].w;
+  c.mat = __float_as_int(t1.w);
   if (COUNT) cn.mat_fetches++;
 }
 
@@ -465,7 +470,7 @@ DEV void trav_step(const DevScene& S, int stack_size, int* __restrict__ stk, Tra
 template <bool COUNT>
 DEV void tri_record_test(const DevScene& S, int k, float4 t0, float4 t1, float4 t2, float4 t3, Trav& t, Counters& cn) {
   int mesh = __float_as_int(t0.w);
-  if (mesh != t.orr.mesh) obj_ray_for(S, mesh, t.o, t.d, t.orr);
+  if (mesh != t.orr.mesh) obj_ray_for(S, mesh, __float_as_int(t2.w), t.o, t.d, t.orr);
   if (COUNT) cn.tri_tests++;
   f3 A = mk3(t0), AB = mk3(t1), AC = mk3(t2), N = mk3(t3);
   float det = -dot3(t.orr.d, N);
@@ -482,7 +487,7 @@ DEV void tri_record_test(const DevScene& S, int k, float4 t0, float4 t1, float4 
   t.c.u = u;
   t.c.v = v;
   t.c.prim = (K_TRI << 28) | (uint32_t)k;
-  t.c.mat = S.meshes[mesh].w;
+  t.c.mat = __float_as_int(t1.w);
   if (COUNT) cn.mat_fetches++;
 }
 
@@ -585,8 +590,7 @@ DEV HitGeom resolve_hit(const DevScene& S, f3 o, f3 d, float t, float u, float v
   } else {  // K_TRI, common.wgsl:224-237
     const float4* tr = S.tris + 6 * (size_t)idx;
     float4 nA = tr[3], nB = tr[4], nC = tr[5];
-    int mesh = (int)nC.w;
-    int gid = S.meshes[mesh].z;
+    int gid = __float_as_int(S.pretri[4 * (size_t)idx + 2].w);  // = meshes[i32(nC.w)].global_id, fetched alongside
     float w = 1.0f - u - v;
     f3 nn = mk3(nA) * w + mk3(nB) * u + mk3(nC) * v;
     g.n = norm3(mat_mul_transposed_dir(S.xforms + 8 * gid + 4, nn));

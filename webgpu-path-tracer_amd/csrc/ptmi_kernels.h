@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
           myslot = cand[ncand - 1u - k];
           float4 r0 = P.in.o[myslot], r1 = P.in.d[myslot];
           float4 h = P.hit[myslot];
-          const uint32_t hmat = P.hitmat[myslot] & HITMAT_ID;
+          const uint32_t hmat = P.hitmat[myslot] & HITMAT_WORD;
           t.o = mk3(r0);
           t.d = mk3(r1);
           t.inv = mk3(1.0f / t.d.x, 1.0f / t.d.y, 1.0f / t.d.z);
@@ -271,15 +271,32 @@ struct NewState {
 // `acc` (by path id) is touched only when it changes or is needed: `acc + emission*T` with emission*T == +-0
 // is `acc` bit for bit (acc is never -0: it starts at +0 and x + y = -0 only for x = y = -0), and with
 // NUM_SAMPLES == 1 the pixel colour (0 + acc) / 1 is `acc` itself.
+// A slot's state and hit record, fetched in one go (seven independent loads in flight).
+struct SlotState {
+  float4 o, d, thr, hit;
+  uint32_t rng, pid, hitmat;
+};
+DEV SlotState load_slot(const Paths& P, uint32_t slot) {
+  SlotState st;
+  st.pid = P.in.pid[slot];
+  st.hitmat = P.hitmat[slot];
+  st.o = P.in.o[slot];
+  st.d = P.in.d[slot];
+  st.thr = P.in.thr[slot];
+  st.rng = P.in.rng[slot];
+  st.hit = P.hit[slot];
+  return st;
+}
+
 template <bool IS>
-DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, uint32_t slot, const QuadL& L, NewState& ns) {
-  const uint32_t pid = P.in.pid[slot];
-  const f3 o = mk3(P.in.o[slot]), d = mk3(P.in.d[slot]);
-  const float4 T4 = P.in.thr[slot];
+DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, const SlotState& st, const QuadL& L, NewState& ns) {
+  const uint32_t pid = st.pid;
+  const f3 o = mk3(st.o), d = mk3(st.d);
+  const float4 T4 = st.thr;
   f3 T = mk3(T4);
   int bounce = __float_as_int(T4.w);
-  uint32_t rng = P.in.rng[slot];
-  const float4 h = P.hit[slot];
+  uint32_t rng = st.rng;
+  const float4 h = st.hit;
 
   bool sample_done = false;
   bool drop_acc = false;     // the sample's radiance is `add` alone (importance-sampling early return, Q8)
@@ -290,7 +307,7 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, uin
     add = mk3(rc.bg[0], rc.bg[1], rc.bg[2]) * T;
     sample_done = true;
   } else {
-    int mat = (int)(P.hitmat[slot] & HITMAT_ID);
+    int mat = (int)(st.hitmat & HITMAT_ID);
     Material m = load_material(S, mat);
     // the chunk is sorted by this class, so `bin` is wave-uniform almost everywhere
     const int bin = (m.type == 0.0f) ? BIN_LAMBERTIAN : (m.type == 1.0f) ? BIN_MIRROR : (m.type == 2.0f) ? BIN_GLASS : (m.type == 3.0f) ? BIN_ISOTROPIC : BIN_OTHER;
@@ -402,17 +419,18 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, uin
 constexpr int kSChunk = 512;  // slots a k_shade block sorts, shades and compacts at a time
 
 // ray_color's loop body for one step, 512 slots at a time per block:
-//   1  LDS counting sort of the chunk by the material class of each slot's hit (ballot ranks), so that the waves
-//      are (almost) uniform in the 4-way material switch of scatterRay.wgsl; holes drop out here;
+//   1  (SORT) LDS counting sort of the chunk by the shade bin in each slot's material word (ballot ranks), so that
+//      the waves are (almost) uniform in the 4-way material switch of scatterRay.wgsl; holes drop out here.  Scenes
+//      whose materials all fall into one bin skip the sort (SORT = false): only misses would diverge, and cheaply;
 //   2  shade_one per slot (state streamed in by slot); survivors' next state is staged in LDS, densely;
 //   3  the staged states are copied to the block's current OUTPUT REGION of the next queue, coalesced.  A block
 //      claims a region with one global atomic (16 or so per launch), fills it across chunks — an entry that does
 //      not fit any more continues in the next region — and marks what is left at the end as holes.
-template <bool IS>
+template <bool IS, bool SORT>
 __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, unsigned long long* __restrict__ totals) {
   __shared__ float4 s_o[kSChunk], s_d[kSChunk], s_thr[kSChunk];
   __shared__ uint32_t s_rng[kSChunk], s_pid[kSChunk];
-  __shared__ uint16_t s_sorted[kSChunk];
+  __shared__ uint16_t s_sorted[SORT ? kSChunk : 1];
   __shared__ uint32_t s_cnt[NUM_BINS + 2];
   __shared__ uint32_t s_nout, s_next, s_cursor, s_rend, s_b0, s_n0, s_b1;
   const QuadL L = load_light(S);
@@ -425,85 +443,106 @@ __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, Re
     s_cursor = 0;
     s_rend = 0;
   }
-  uint32_t my_valid = 0;  // thread 0: slots holding a path seen by this block (= hitScene invocations)
+  uint32_t my_valid = 0;  // lane 0 of a wave: slots holding a path seen so far (= hitScene invocations)
+  // stage one survivor per lane in LDS, densely (one LDS atomic per wave)
+  auto stage = [&](bool survive, const NewState& ns) {
+    const uint64_t mk = __ballot(survive);
+    if (mk) {
+      const int leader = __ffsll((unsigned long long)mk) - 1;
+      uint32_t bb = 0;
+      if (lane == leader) bb = atomicAdd(&s_nout, (uint32_t)__popcll(mk));
+      bb = (uint32_t)__shfl((int)bb, leader, 64);
+      if (survive) {
+        const uint32_t q = bb + lanes_below(mk);
+        s_o[q] = make_float4(ns.o.x, ns.o.y, ns.o.z, 0.0f);
+        s_d[q] = make_float4(ns.d.x, ns.d.y, ns.d.z, 0.0f);
+        s_thr[q] = make_float4(ns.T.x, ns.T.y, ns.T.z, __int_as_float(ns.bounce));
+        s_rng[q] = ns.rng;
+        s_pid[q] = ns.pid;
+      }
+    }
+  };
   for (uint32_t base = blockIdx.x * (uint32_t)kSChunk; base < n; base += gridDim.x * (uint32_t)kSChunk) {
     const uint32_t m = min((uint32_t)kSChunk, n - base);
-    if (threadIdx.x < NUM_BINS) s_cnt[threadIdx.x] = 0;
+    if (SORT && threadIdx.x < NUM_BINS) s_cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
       s_nout = 0;
       s_next = 0;
     }
     __syncthreads();
-    // ---- 1: sort ----
-    uint32_t keys[kSChunk / kBlock];
-#pragma unroll
-    for (int r = 0; r < kSChunk / kBlock; r++) {
-      const uint32_t j = (uint32_t)r * kBlock + threadIdx.x;
-      int bin = -1;
-      if (j < m) {
-        const uint32_t hmat = P.hitmat[base + j] & HITMAT_ID;
-        if (hmat == HITMAT_MISS) {
-          bin = BIN_MISS;
-        } else if (hmat != HITMAT_HOLE) {
-          const float ty = S.mats[4 * (int)hmat + 3].z;
-          bin = (ty == 0.0f) ? BIN_LAMBERTIAN : (ty == 1.0f) ? BIN_MIRROR : (ty == 2.0f) ? BIN_GLASS : (ty == 3.0f) ? BIN_ISOTROPIC : BIN_OTHER;
-        }
-      }
-      uint32_t rank = 0;
-      if ((uint32_t)r * kBlock < m) rank = bin_rank(bin, s_cnt);  // block-uniform condition
-      keys[r] = (bin < 0) ? 0xffffffffu : ((uint32_t)bin | (rank << 3));
-    }
-    __syncthreads();
-    uint32_t nvalid = 0;
-    {
-      uint32_t off[NUM_BINS];
-#pragma unroll
-      for (int b = 0; b < NUM_BINS; b++) {
-        off[b] = nvalid;
-        nvalid += s_cnt[b];
-      }
+    if (SORT) {
+      // ---- 1: sort ----
+      uint32_t keys[kSChunk / kBlock];
 #pragma unroll
       for (int r = 0; r < kSChunk / kBlock; r++) {
-        if (keys[r] != 0xffffffffu) {
-          const uint32_t b = keys[r] & 7u;
-          uint32_t o = off[0];
+        const uint32_t j = (uint32_t)r * kBlock + threadIdx.x;
+        int bin = -1;
+        if (j < m) {
+          const uint32_t b = (P.hitmat[base + j] >> HITMAT_BIN_SHIFT) & 7u;
+          if (b < (uint32_t)NUM_BINS) bin = (int)b;  // 7 = hole
+        }
+        uint32_t rank = 0;
+        if ((uint32_t)r * kBlock < m) rank = bin_rank(bin, s_cnt);  // block-uniform condition
+        keys[r] = (bin < 0) ? 0xffffffffu : ((uint32_t)bin | (rank << 3));
+      }
+      __syncthreads();
+      uint32_t nvalid = 0;
+      {
+        uint32_t off[NUM_BINS];
 #pragma unroll
-          for (int k = 1; k < NUM_BINS; k++) o = (b == (uint32_t)k) ? off[k] : o;
-          s_sorted[o + (keys[r] >> 3)] = (uint16_t)((uint32_t)r * kBlock + threadIdx.x);
+        for (int b = 0; b < NUM_BINS; b++) {
+          off[b] = nvalid;
+          nvalid += s_cnt[b];
+        }
+#pragma unroll
+        for (int r = 0; r < kSChunk / kBlock; r++) {
+          if (keys[r] != 0xffffffffu) {
+            const uint32_t b = keys[r] & 7u;
+            uint32_t o = off[0];
+#pragma unroll
+            for (int k = 1; k < NUM_BINS; k++) o = (b == (uint32_t)k) ? off[k] : o;
+            s_sorted[o + (keys[r] >> 3)] = (uint16_t)((uint32_t)r * kBlock + threadIdx.x);
+          }
         }
       }
-    }
-    my_valid += nvalid;
-    __syncthreads();
-    // ---- 2: shade, stage survivors ----
-    // waves take 64-entry groups dynamically: the sort puts the cheap MISS entries last, static rounds would leave
-    // the waves that got them idle at the barrier
+      if (threadIdx.x == 0) my_valid += nvalid;
+      __syncthreads();
+      // ---- 2: shade, stage survivors ----
+      // waves take 64-entry groups dynamically: the sort puts the cheap MISS entries last, static rounds would leave
+      // the waves that got them idle at the barrier
 #pragma unroll 1
-    for (;;) {
-      uint32_t k0 = 0;
-      if (lane == 0) k0 = atomicAdd(&s_next, 64u);
-      k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)k0);
-      if (k0 >= nvalid) break;
-      const uint32_t k = k0 + lane;
-      bool survive = false;
-      NewState ns;
-      ns.o = ns.d = ns.T = mk3(0, 0, 0);
-      ns.bounce = 0, ns.rng = 0, ns.pid = 0;
-      if (k < nvalid) survive = shade_one<IS>(S, rc, P, base + s_sorted[k], L, ns);
-      const uint64_t mk = __ballot(survive);
-      if (mk) {
-        const int leader = __ffsll((unsigned long long)mk) - 1;
-        uint32_t bb = 0;
-        if (lane == leader) bb = atomicAdd(&s_nout, (uint32_t)__popcll(mk));
-        bb = (uint32_t)__shfl((int)bb, leader, 64);
-        if (survive) {
-          const uint32_t q = bb + lanes_below(mk);
-          s_o[q] = make_float4(ns.o.x, ns.o.y, ns.o.z, 0.0f);
-          s_d[q] = make_float4(ns.d.x, ns.d.y, ns.d.z, 0.0f);
-          s_thr[q] = make_float4(ns.T.x, ns.T.y, ns.T.z, __int_as_float(ns.bounce));
-          s_rng[q] = ns.rng;
-          s_pid[q] = ns.pid;
+      for (;;) {
+        uint32_t k0 = 0;
+        if (lane == 0) k0 = atomicAdd(&s_next, 64u);
+        k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)k0);
+        if (k0 >= nvalid) break;
+        const uint32_t k = k0 + lane;
+        bool survive = false;
+        NewState ns;
+        ns.o = ns.d = ns.T = mk3(0, 0, 0);
+        ns.bounce = 0, ns.rng = 0, ns.pid = 0;
+        if (k < nvalid) {
+          const SlotState st = load_slot(P, base + s_sorted[k]);
+          survive = shade_one<IS>(S, rc, P, st, L, ns);
         }
+        stage(survive, ns);
+      }
+    } else {
+      // ---- 2 (unsorted): slots in queue order; a hole's loads are simply ignored ----
+#pragma unroll 1
+      for (uint32_t j0 = (threadIdx.x & ~63u); j0 < m; j0 += kBlock) {
+        const uint32_t j = j0 + lane;
+        bool survive = false, valid = false;
+        NewState ns;
+        ns.o = ns.d = ns.T = mk3(0, 0, 0);
+        ns.bounce = 0, ns.rng = 0, ns.pid = 0;
+        if (j < m) {
+          const SlotState st = load_slot(P, base + j);
+          valid = st.pid != PID_HOLE;
+          if (valid) survive = shade_one<IS>(S, rc, P, st, L, ns);
+        }
+        my_valid += (uint32_t)__popcll(__ballot(valid));
+        stage(survive, ns);
       }
     }
     __syncthreads();
@@ -547,7 +586,7 @@ __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, Re
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0 && my_valid) atomicAdd(&ctl->n_valid, my_valid);
+  if (lane == 0 && my_valid) atomicAdd(&ctl->n_valid, my_valid);
   // what is left of the last region becomes holes
   __syncthreads();
   for (uint32_t i = s_cursor + threadIdx.x; i < s_rend; i += kBlock) P.out.pid[i] = PID_HOLE;
