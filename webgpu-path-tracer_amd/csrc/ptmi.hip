@@ -74,8 +74,8 @@ struct ptmi_ctx {
   size_t path_cap = 0;
   bool pixsum_alloc = false;
   size_t slot_cap = 0;  // slots per queue buffer (paths + room for the holes k_shade's regions leave)
-  DBuf d_so[2], d_sd[2], d_sthr[2], d_srng[2], d_spid[2];  // slot-indexed live state, ping-pong
-  DBuf d_acc, d_pixsum, d_hit, d_hitmat, d_ctl, d_totals, d_scratch;
+  DBuf d_q0[2], d_q1[2], d_q2[2], d_tp[2], d_hm[2];  // slot-indexed live state and hit records, ping-pong
+  DBuf d_uv, d_acc, d_pixsum, d_ctl, d_totals, d_scratch;
   int traversal_mode = 0;  // 0 auto, 1 while-while, 2 flat
   int ctl_cap = 0;
 
@@ -377,14 +377,13 @@ int ensure_paths(ptmi_ctx* c, size_t npaths, int n_ctl, bool need_pixsum) {
     // (region <= slots/grid/16 rounded up to 512) — 1/8 of the paths plus 1024 slots per possible block is ample.
     const size_t slots = npaths + npaths / 8 + (size_t)c->num_cus * 8 * 1024;
     for (int k = 0; k < 2; k++) {
-      HIP_TRY(c, c->d_so[k].ensure(slots * 16));
-      HIP_TRY(c, c->d_sd[k].ensure(slots * 16));
-      HIP_TRY(c, c->d_sthr[k].ensure(slots * 16));
-      HIP_TRY(c, c->d_srng[k].ensure(slots * 4));
-      HIP_TRY(c, c->d_spid[k].ensure(slots * 4));
+      HIP_TRY(c, c->d_q0[k].ensure(slots * 16));
+      HIP_TRY(c, c->d_q1[k].ensure(slots * 16));
+      HIP_TRY(c, c->d_q2[k].ensure(slots * 16));
+      HIP_TRY(c, c->d_tp[k].ensure(slots * 8));
+      HIP_TRY(c, c->d_hm[k].ensure(slots * 4));
     }
-    HIP_TRY(c, c->d_hit.ensure(slots * 16));
-    HIP_TRY(c, c->d_hitmat.ensure(slots * 4));
+    HIP_TRY(c, c->d_uv.ensure(slots * 8));
     HIP_TRY(c, c->d_acc.ensure(npaths * 16));
     c->path_cap = npaths;
     c->slot_cap = slots;
@@ -409,10 +408,11 @@ int ensure_paths(ptmi_ctx* c, size_t npaths, int n_ctl, bool need_pixsum) {
 Paths paths_of(ptmi_ctx* c, int step, bool with_pixsum) {
   Paths P;
   const int a = step & 1, b = a ^ 1;
-  P.in = Slots{c->d_so[a].as<float4>(), c->d_sd[a].as<float4>(), c->d_sthr[a].as<float4>(), c->d_srng[a].as<uint32_t>(), c->d_spid[a].as<uint32_t>()};
-  P.out = Slots{c->d_so[b].as<float4>(), c->d_sd[b].as<float4>(), c->d_sthr[b].as<float4>(), c->d_srng[b].as<uint32_t>(), c->d_spid[b].as<uint32_t>()};
-  P.hit = c->d_hit.as<float4>();
-  P.hitmat = c->d_hitmat.as<uint32_t>();
+  P.in = Slots{c->d_q0[a].as<float4>(), c->d_q1[a].as<float4>(), c->d_q2[a].as<float4>()};
+  P.out = Slots{c->d_q0[b].as<float4>(), c->d_q1[b].as<float4>(), c->d_q2[b].as<float4>()};
+  P.hin = HitBuf{c->d_tp[a].as<float2>(), c->d_hm[a].as<uint32_t>()};
+  P.hout = HitBuf{c->d_tp[b].as<float2>(), c->d_hm[b].as<uint32_t>()};
+  P.uv = c->d_uv.as<float2>();
   P.acc = c->d_acc.as<float4>();
   P.pixsum = with_pixsum ? c->d_pixsum.as<float4>() : nullptr;
   P.cap = (uint32_t)c->slot_cap;
@@ -431,11 +431,12 @@ int env_int(const char* name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 
-// hitScene for the step's queue: k_prims (element-wise part, flags the rays that enter the root box) then k_bvh.
-int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_items) {
+// hitScene, part 2 for the step's queue (k_bvh).  Part 1 has already been run by whoever created the rays (k_generate,
+// k_shade); ptmi_trace's rays come from the host, so it asks for k_prims first.
+int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_items, bool with_prims) {
   unsigned long long* tot = c->d_totals.as<unsigned long long>();
   const uint32_t pgrid = std::max<uint32_t>(1, std::min<uint32_t>((max_items + kBlock - 1) / kBlock, (uint32_t)c->num_cus * 32));
-  {
+  if (with_prims) {
     ScopedSpan sp(c, T_PRIMS);
     if (c->counters) hipLaunchKernelGGL(k_prims<true>, dim3(pgrid), dim3(kBlock), 0, c->stream, c->S, P, ctl, tot);
     else hipLaunchKernelGGL(k_prims<false>, dim3(pgrid), dim3(kBlock), 0, c->stream, c->S, P, ctl, tot);
@@ -517,7 +518,8 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   {
     ScopedSpan s(c, T_OTHER);
     HIP_TRY(c, hipMemsetAsync(ctl, 0, (size_t)(n_steps + 2) * sizeof(StepCtl), c->stream));
-    hipLaunchKernelGGL(k_generate, dim3(ew_grid), dim3(kBlock), 0, c->stream, rc, paths_of(c, 0, rc.num_samples > 1), ctl);
+    if (c->counters) hipLaunchKernelGGL(k_generate<true>, dim3(ew_grid), dim3(kBlock), 0, c->stream, c->S, rc, paths_of(c, 0, rc.num_samples > 1), ctl, tot);
+    else hipLaunchKernelGGL(k_generate<false>, dim3(ew_grid), dim3(kBlock), 0, c->stream, c->S, rc, paths_of(c, 0, rc.num_samples > 1), ctl, tot);
   }
   for (int s = 0; s < n_steps; s++) {
     // With the reference's MAX_BOUNCES = 100 nearly all steps run on an empty queue (Russian roulette ends paths after
@@ -530,19 +532,25 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
     }
     Paths P = paths_of(c, s, rc.num_samples > 1);
     {
-      int lr = launch_intersect(c, P, ctl + s, bound);
+      int lr = launch_intersect(c, P, ctl + s, bound, false);
       if (lr) return lr;
     }
     {
       ScopedSpan sp(c, T_SHADE);
-#define PTMI_LAUNCH_SHADE(IS, SO) hipLaunchKernelGGL((k_shade<IS, SO>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, tot)
+#define PTMI_LAUNCH_SHADE(IS, SO, CN) hipLaunchKernelGGL((k_shade<IS, SO, CN>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, tot)
+#define PTMI_LAUNCH_SHADE2(IS, SO) \
+  do {                             \
+    if (c->counters) PTMI_LAUNCH_SHADE(IS, SO, true); \
+    else PTMI_LAUNCH_SHADE(IS, SO, false);            \
+  } while (0)
       if (p.importance_sampling) {
-        if (sort) PTMI_LAUNCH_SHADE(true, true);
-        else PTMI_LAUNCH_SHADE(true, false);
+        if (sort) PTMI_LAUNCH_SHADE2(true, true);
+        else PTMI_LAUNCH_SHADE2(true, false);
       } else {
-        if (sort) PTMI_LAUNCH_SHADE(false, true);
-        else PTMI_LAUNCH_SHADE(false, false);
+        if (sort) PTMI_LAUNCH_SHADE2(false, true);
+        else PTMI_LAUNCH_SHADE2(false, false);
       }
+#undef PTMI_LAUNCH_SHADE2
 #undef PTMI_LAUNCH_SHADE
     }
     c->stats.intersect_launches++;
@@ -640,9 +648,9 @@ void ptmi_destroy(ptmi_ctx* c) {
   drain_spans(c);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (DBuf* b : {&c->d_spheres, &c->d_sphere_info, &c->d_quads, &c->d_quad_mat, &c->d_tris, &c->d_pretri, &c->d_meshes, &c->d_xforms,
-                  &c->d_mats, &c->d_pairs, &c->d_leaf_table, &c->d_fb_own, &c->d_so[0], &c->d_so[1], &c->d_sd[0], &c->d_sd[1], &c->d_sthr[0],
-                  &c->d_sthr[1], &c->d_srng[0], &c->d_srng[1], &c->d_spid[0], &c->d_spid[1], &c->d_acc, &c->d_pixsum, &c->d_hit, &c->d_hitmat,
-                  &c->d_ctl, &c->d_totals, &c->d_scratch})
+                  &c->d_mats, &c->d_pairs, &c->d_leaf_table, &c->d_fb_own, &c->d_q0[0], &c->d_q0[1], &c->d_q1[0], &c->d_q1[1], &c->d_q2[0],
+                  &c->d_q2[1], &c->d_tp[0], &c->d_tp[1], &c->d_hm[0], &c->d_hm[1], &c->d_uv, &c->d_acc, &c->d_pixsum, &c->d_ctl, &c->d_totals,
+                  &c->d_scratch})
     b->release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -870,28 +878,28 @@ int ptmi_trace(ptmi_ctx* c, size_t n, const float* rays6, uint32_t* rng_inout, p
   Paths P = paths_of(c, 0, false);
   // stage: one slot per ray (slot i = path i)
   std::vector<float> so(4 * n, 0.0f), sd(4 * n, 0.0f);
-  std::vector<uint32_t> ident(n), rng(n, 0u);
   for (size_t i = 0; i < n; i++) {
     for (int k = 0; k < 3; k++) so[4 * i + k] = rays6[6 * i + k], sd[4 * i + k] = rays6[6 * i + 3 + k];
-    ident[i] = (uint32_t)i;
-    if (rng_inout) rng[i] = rng_inout[i];
+    const uint32_t ident = (uint32_t)i, rng = rng_inout ? rng_inout[i] : 0u;
+    memcpy(&so[4 * i + 3], &rng, 4);
+    memcpy(&sd[4 * i + 3], &ident, 4);
   }
   StepCtl ctl0{};
   ctl0.n_rays = (uint32_t)n;
   StepCtl* ctl = c->d_ctl.as<StepCtl>();
-  HIP_TRY(c, hipMemcpyAsync(P.in.o, so.data(), so.size() * 4, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(P.in.d, sd.data(), sd.size() * 4, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(P.in.rng, rng.data(), n * 4, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(P.in.pid, ident.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(P.in.q0, so.data(), so.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(P.in.q1, sd.data(), sd.size() * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(ctl, &ctl0, sizeof ctl0, hipMemcpyHostToDevice, c->stream));
-  r = launch_intersect(c, P, ctl, (uint32_t)n);
+  r = launch_intersect(c, P, ctl, (uint32_t)n, true);
   if (r) return r;
   HIP_TRY(c, c->d_scratch.ensure(n * sizeof(HitOut)));
   hipLaunchKernelGGL(k_resolve_hits, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->S, P, (uint32_t)n, c->d_scratch.as<HitOut>());
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(out, c->d_scratch.p, n * sizeof(HitOut), hipMemcpyDeviceToHost, c->stream));
-  if (rng_inout) HIP_TRY(c, hipMemcpyAsync(rng_inout, P.in.rng, n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (rng_inout) HIP_TRY(c, hipMemcpyAsync(so.data(), P.in.q0, so.size() * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (rng_inout)
+    for (size_t i = 0; i < n; i++) memcpy(&rng_inout[i], &so[4 * i + 3], 4);
   return PTMI_OK;
 }
 

@@ -111,8 +111,9 @@ struct DevScene {
 
 // ---- path state ----------------------------------------------------------------------------------------
 // Live state is indexed by QUEUE SLOT and compacted every step: step s reads the `in` buffers, k_shade writes the
-// survivors densely into the `out` buffers (= `in` of step s+1), so every kernel streams its state coalesced
-// instead of gathering by path id.  Slots can be holes (pid == PID_HOLE): a block of k_shade claims output space in
+// survivors densely into the `out` buffers (= `in` of step s+1) TOGETHER with the first part of their next hitScene
+// (spheres, quads, root box), so every kernel streams its state coalesced instead of gathering by path id, and a
+// ray's state crosses HBM once per bounce in each direction.  Slots can be holes (pid == PID_HOLE): a block of k_shade claims output space in
 // regions and marks what it did not use.  The hit record belongs to the slot of `in`.  Radiance (`acc`) stays
 // indexed by path id = frame_slot * n_local + local pixel index: it changes rarely (emissive hits, misses) and k_accumulate needs it
 // by pixel.
@@ -124,17 +125,19 @@ constexpr uint32_t HITMAT_MISS = ((uint32_t)BIN_MISS << HITMAT_BIN_SHIFT) | 0x0f
 constexpr uint32_t HITMAT_HOLE = (7u << HITMAT_BIN_SHIFT) | 0x0ffffffeu;                   // slot holds no path
 constexpr uint32_t HITMAT_BVH = 0x80000000u;   // flag: the ray entered the root box, k_bvh still has to traverse it
 
-struct Slots {
-  float4* o;      // {origin.xyz, -}
-  float4* d;      // {dir.xyz, -}
-  float4* thr;    // {T.xyz, bounce index as int bits}
-  uint32_t* rng;  // randState
-  uint32_t* pid;  // path id, or PID_HOLE
+struct Slots {     // 48 bytes of live state per slot
+  float4* q0;      // {origin.xyz, randState bits}
+  float4* q1;      // {dir.xyz, path id bits — PID_HOLE = no path}
+  float4* q2;      // {throughput.xyz, bounce index bits}
+};
+struct HitBuf {    // hitScene's result for the ray in the same slot: 12 bytes, plus 8 more for a triangle hit
+  float2* tp;      // {t, kind<<28 | index}
+  uint32_t* mat;   // effective material word (after hit_volume's clobber, Q3) / MISS / HOLE, | HITMAT_BVH
 };
 struct Paths {
-  Slots in, out;
-  float4* hit;       // by slot of `in`: {t, u, v, kind<<28 | index}
-  uint32_t* hitmat;  // by slot of `in`: effective material id (after hit_volume's clobber, Q3) / MISS / HOLE
+  Slots in, out;     // this step's queue, next step's queue
+  HitBuf hin, hout;  // hit records of `in` (k_generate / the previous k_shade + k_bvh), of `out` (this k_shade)
+  float2* uv;        // by slot of `in`: barycentrics, written by k_bvh and read by k_shade for triangle hits only
   float4* acc;       // by path id: {acc_radiance.xyz, sample index as int bits}; the final pixel colour at the end
   float4* pixsum;    // by path id: {pixColor.xyz, -}  (num_samples > 1 only)
   uint32_t cap;      // slots per queue buffer
@@ -323,6 +326,27 @@ DEV bool hit_aabb(float4 lo, float4 hi, float tmax, f3 o, f3 inv) {
   float t_min = ptm_max(kTmin, ptm_max(sx, ptm_max(sy, sz)));
   float t_max = ptm_min(tmax, ptm_min(bx, ptm_min(by, bz)));
   return t_max > t_min;
+}
+
+// hitScene, part 1 (hitRay.wgsl:6-54): spheres, quads and the ROOT box test of the BVH loop's first iteration.  A ray
+// that enters the root box gets HITMAT_BVH set in its material word: k_bvh finds its work by scanning those flags.
+template <bool COUNT>
+DEV void prims_for_ray(const DevScene& S, f3 o, f3 d, uint32_t& rng, float2& tp, uint32_t& hitmat, Counters& cn) {
+  Closest c;
+  c.t = kMaxFloat;
+  c.u = c.v = 0.0f;
+  c.prim = K_NONE;
+  c.mat = 0;
+  if (S.n_spheres > 0) hit_spheres<COUNT>(S, o, d, rng, c, cn);
+  hit_quads<COUNT>(S, o, d, c, cn);
+  bool to_bvh = false;
+  if (S.n_nodes > 0) {
+    if (COUNT) cn.node_visits++;
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    to_bvh = hit_aabb(S.root_lo, S.root_hi, c.t, o, inv);
+  }
+  tp = make_float2(c.t, __uint_as_float(c.prim));
+  hitmat = (((c.prim >> 28) != K_NONE) ? (uint32_t)c.mat : HITMAT_MISS) | (to_bvh ? HITMAT_BVH : 0u);
 }
 
 // Object-space ray of shaders/common.wgsl:193-197, cached per mesh (it is a pure function of the

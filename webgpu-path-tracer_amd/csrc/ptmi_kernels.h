@@ -1,14 +1,14 @@
 // ptmi_kernels.h — the wavefront integrator's kernels (gfx950).
 //
 //   k_generate   one thread per (frame slot, owned pixel): seeds the RNG (main.wgsl:16), builds the camera ray
-//                (shootRay.wgsl), fills step 0's queue (slot = path id).
-//   k_prims      hitScene part 1 (hitRay.wgsl:6-54): spheres, quads, root-box test for every queue slot — element-wise,
-//                streaming; flags the rays that enter the root box.
+//                (shootRay.wgsl), runs hitScene part 1 on it, fills step 0's queue (slot = path id).
 //   k_bvh        hitScene part 2 (hitRay.wgsl:42-110): persistent single-wave blocks, one ray per lane, LDS traversal
 //                stacks, ballot-based lane refill by scanning the flags; no barriers, tails only at kernel end.
 //   k_shade      per 512-slot chunk: LDS counting sort by material class (bin-uniform waves), ray_color's loop body
 //                (traceRay.wgsl:10-80) + material_scatter + Russian roulette; the survivors' next state is staged in
-//                LDS and written densely into the next step's queue (path state is compacted every step).
+//                LDS, gets hitScene part 1 (hitRay.wgsl:6-54: spheres, quads, root box) for the NEW ray and is written
+//                densely into the next step's queue (path state is compacted every step).
+//   k_prims      hitScene part 1 as a kernel of its own: only ptmi_trace needs it.
 //   k_accumulate framebuffer read-modify-write of main.wgsl:22-27 for every frame slot, in frame order.
 #pragma once
 #include "ptmi_device.h"
@@ -17,8 +17,25 @@ namespace ptmi {
 
 constexpr int kBlock = 256;
 
-__global__ __launch_bounds__(kBlock) void k_generate(RenderConst rc, Paths P, StepCtl* __restrict__ ctl) {
+DEV void reduce_counters(const Counters& cn, unsigned long long* __restrict__ totals, bool bvh) {
+  uint32_t v[5] = {cn.node_visits, cn.tri_tests, cn.sphere_tests, cn.quad_tests, cn.mat_fetches};
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    unsigned long long x = v[k];
+    for (int off2 = 32; off2 > 0; off2 >>= 1) x += __shfl_down(x, off2, 64);
+    if (lane_id() == 0 && x) {
+      atomicAdd(&totals[2 + k], x);
+      if (bvh && k == 0) atomicAdd(&totals[7], x);  // node visits below the root
+      if (bvh && k == 4) atomicAdd(&totals[8], x);  // accepted triangle hits
+    }
+  }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_generate(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, unsigned long long* __restrict__ totals) {
+  const bool trace = rc.max_bounces > 0;  // MAX_BOUNCES = 0: ray_color's loop body never runs, no hitScene at all
   uint32_t total = rc.n_local * (uint32_t)rc.n_frames;
+  Counters cn = {0, 0, 0, 0, 0};
   for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < total; g += gridDim.x * kBlock) {
     uint32_t f = g / rc.n_local, j = g - f * rc.n_local;
     uint32_t pix = local_to_pixel(rc, j);
@@ -27,15 +44,19 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderConst rc, Paths P, St
     uint32_t rng = pix + (uint32_t)(float)(rc.frame0 + f) * 719393u;
     f3 o, d;
     camera_ray(rc, pix, 0, rng, o, d);
-    P.in.o[g] = make_float4(o.x, o.y, o.z, 0.0f);
-    P.in.d[g] = make_float4(d.x, d.y, d.z, 0.0f);
-    P.in.thr[g] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0));
-    P.in.rng[g] = rng;
-    P.in.pid[g] = pid;
+    float2 tp = make_float2(0.0f, 0.0f);
+    uint32_t hm = HITMAT_MISS;
+    if (trace) prims_for_ray<COUNT>(S, o, d, rng, tp, hm, cn);
+    P.in.q0[g] = make_float4(o.x, o.y, o.z, __uint_as_float(rng));
+    P.in.q1[g] = make_float4(d.x, d.y, d.z, __uint_as_float(pid));
+    P.in.q2[g] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0));
+    P.hin.tp[g] = tp;
+    P.hin.mat[g] = hm;
     P.acc[pid] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(0));
     if (P.pixsum) P.pixsum[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) ctl[0].n_rays = total;
+  if (COUNT) reduce_counters(cn, totals, false);
 }
 
 // 96 VGPRs (5 waves/SIMD, no spills) measured 27 % faster than the compiler's default 106 VGPRs / 4 waves: the kernel
@@ -66,52 +87,28 @@ DEV uint32_t bin_rank(int bin, uint32_t* s_cnt) {
   return rank;
 }
 
-// hitScene, part 1 (hitRay.wgsl:6-54): spheres, quads and the ROOT box test for every slot of the step's queue.
-// Purely element-wise: one slot per thread, state streamed by slot, primitive tables in SGPRs, no LDS, no atomics —
-// latency is hidden by sheer parallelism.  A ray that enters the root box gets HITMAT_BVH set in its hitmat word;
-// k_bvh finds its work by scanning those flags.
+// hitScene, part 1 as a stand-alone, element-wise kernel (one slot per thread): ptmi_trace's entry into the pipeline.
+// Renders never launch it — k_generate and k_shade run prims_for_ray on the rays they create.
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_prims(DevScene S, Paths P, const StepCtl* __restrict__ ctl, unsigned long long* __restrict__ totals) {
   const uint32_t n = ctl->n_rays;
-  const bool have_bvh = S.n_nodes > 0;
   Counters cn = {0, 0, 0, 0, 0};
   for (uint32_t slot = blockIdx.x * kBlock + threadIdx.x; slot < n; slot += gridDim.x * kBlock) {
-    const uint32_t pid = P.in.pid[slot];
-    if (pid == PID_HOLE) {
-      P.hitmat[slot] = HITMAT_HOLE;
+    const float4 a0 = P.in.q0[slot], a1 = P.in.q1[slot];
+    if (__float_as_uint(a1.w) == PID_HOLE) {
+      P.hin.mat[slot] = HITMAT_HOLE;
       continue;
     }
-    f3 o = mk3(P.in.o[slot]), d = mk3(P.in.d[slot]);
-    Closest c;
-    c.t = kMaxFloat;
-    c.u = c.v = 0.0f;
-    c.prim = K_NONE;
-    c.mat = 0;
-    if (S.n_spheres > 0) {
-      uint32_t rng = P.in.rng[slot];
-      uint32_t rng0 = rng;
-      hit_spheres<COUNT>(S, o, d, rng, c, cn);
-      if (rng != rng0) P.in.rng[slot] = rng;
-    }
-    hit_quads<COUNT>(S, o, d, c, cn);
-    bool to_bvh = false;
-    if (have_bvh) {
-      if (COUNT) cn.node_visits++;
-      const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-      to_bvh = hit_aabb(S.root_lo, S.root_hi, c.t, o, inv);
-    }
-    P.hit[slot] = make_float4(c.t, c.u, c.v, __uint_as_float(c.prim));
-    P.hitmat[slot] = (((c.prim >> 28) != K_NONE) ? (uint32_t)c.mat : HITMAT_MISS) | (to_bvh ? HITMAT_BVH : 0u);
+    uint32_t rng = __float_as_uint(a0.w);
+    const uint32_t rng0 = rng;
+    float2 tp;
+    uint32_t hm;
+    prims_for_ray<COUNT>(S, mk3(a0), mk3(a1), rng, tp, hm, cn);
+    if (rng != rng0) P.in.q0[slot] = make_float4(a0.x, a0.y, a0.z, __uint_as_float(rng));
+    P.hin.tp[slot] = tp;
+    P.hin.mat[slot] = hm;
   }
-  if (COUNT) {
-    uint32_t v[5] = {cn.node_visits, cn.tri_tests, cn.sphere_tests, cn.quad_tests, cn.mat_fetches};
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-      unsigned long long x = v[k];
-      for (int off2 = 32; off2 > 0; off2 >>= 1) x += __shfl_down(x, off2, 64);
-      if (lane_id() == 0 && x) atomicAdd(&totals[2 + k], x);
-    }
-  }
+  if (COUNT) reduce_counters(cn, totals, false);
 }
 
 // A wave refills its idle lanes once this many lanes are idle (or all are).
@@ -159,8 +156,11 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
   for (;;) {
     // retire finished rays (stores only: nothing here waits on memory)
     if (has && t.cur == T_DONE && t.pending == 0u) {
-      P.hit[myslot] = make_float4(t.c.t, t.c.u, t.c.v, __uint_as_float(t.c.prim));
-      P.hitmat[myslot] = ((t.c.prim >> 28) != K_NONE) ? (uint32_t)t.c.mat : HITMAT_MISS;
+      if ((t.c.prim >> 28) == K_TRI) {  // a triangle beat what part 1 had found; otherwise the record stands as it is
+        P.hin.tp[myslot] = make_float2(t.c.t, __uint_as_float(t.c.prim));
+        P.uv[myslot] = make_float2(t.c.u, t.c.v);
+        P.hin.mat[myslot] = (uint32_t)t.c.mat;
+      }
       has = false;
     }
     uint64_t hm = __ballot(has);
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
           re = min(nb + range, n);
         }
         const uint32_t slot = rb + (uint32_t)lane;
-        const bool flagged = slot < re && (P.hitmat[slot] & HITMAT_BVH) != 0u;
+        const bool flagged = slot < re && (P.hin.mat[slot] & HITMAT_BVH) != 0u;
         const uint64_t fm = __ballot(flagged);
         if (flagged) cand[ncand + lanes_below(fm)] = slot;
         ncand += (uint32_t)__popcll(fm);
@@ -193,14 +193,14 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
         const uint32_t take = min(ncand, want);
         if (!has && k < take) {
           myslot = cand[ncand - 1u - k];
-          float4 r0 = P.in.o[myslot], r1 = P.in.d[myslot];
-          float4 h = P.hit[myslot];
-          const uint32_t hmat = P.hitmat[myslot] & HITMAT_WORD;
+          float4 r0 = P.in.q0[myslot], r1 = P.in.q1[myslot];
+          float2 h = P.hin.tp[myslot];
+          const uint32_t hmat = P.hin.mat[myslot] & HITMAT_WORD;
           t.o = mk3(r0);
           t.d = mk3(r1);
           t.inv = mk3(1.0f / t.d.x, 1.0f / t.d.y, 1.0f / t.d.z);
           t.negmask = (t.d.x < 0 ? 1u : 0u) | (t.d.y < 0 ? 2u : 0u) | (t.d.z < 0 ? 4u : 0u);
-          t.c.t = h.x, t.c.u = h.y, t.c.v = h.z, t.c.prim = __float_as_uint(h.w);
+          t.c.t = h.x, t.c.u = 0.0f, t.c.v = 0.0f, t.c.prim = __float_as_uint(h.y);
           t.c.mat = (hmat != HITMAT_MISS) ? (int)hmat : 0;
           t.orr.mesh = -1;
           t.sp = 0;
@@ -244,19 +244,7 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
       } while (working >= min_working);
     }
   }
-  if (COUNT) {
-    uint32_t v[5] = {cn.node_visits, cn.tri_tests, cn.sphere_tests, cn.quad_tests, cn.mat_fetches};
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-      unsigned long long x = v[k];
-      for (int off2 = 32; off2 > 0; off2 >>= 1) x += __shfl_down(x, off2, 64);
-      if (lane == 0 && x) {
-        atomicAdd(&totals[2 + k], x);
-        if (k == 0) atomicAdd(&totals[7], x);  // node visits below the root
-        if (k == 4) atomicAdd(&totals[8], x);  // accepted triangle hits
-      }
-    }
-  }
+  if (COUNT) reduce_counters(cn, totals, true);
 }
 
 // What a surviving path carries into the next step's queue.
@@ -273,37 +261,37 @@ struct NewState {
 // NUM_SAMPLES == 1 the pixel colour (0 + acc) / 1 is `acc` itself.
 // A slot's state and hit record, fetched in one go (seven independent loads in flight).
 struct SlotState {
-  float4 o, d, thr, hit;
-  uint32_t rng, pid, hitmat;
+  float4 q0, q1, q2;
+  float2 tp;
+  uint32_t hitmat, slot;
 };
 DEV SlotState load_slot(const Paths& P, uint32_t slot) {
   SlotState st;
-  st.pid = P.in.pid[slot];
-  st.hitmat = P.hitmat[slot];
-  st.o = P.in.o[slot];
-  st.d = P.in.d[slot];
-  st.thr = P.in.thr[slot];
-  st.rng = P.in.rng[slot];
-  st.hit = P.hit[slot];
+  st.slot = slot;
+  st.hitmat = P.hin.mat[slot];
+  st.q1 = P.in.q1[slot];
+  st.q0 = P.in.q0[slot];
+  st.q2 = P.in.q2[slot];
+  st.tp = P.hin.tp[slot];
   return st;
 }
 
 template <bool IS>
 DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, const SlotState& st, const QuadL& L, NewState& ns) {
-  const uint32_t pid = st.pid;
-  const f3 o = mk3(st.o), d = mk3(st.d);
-  const float4 T4 = st.thr;
+  const uint32_t pid = __float_as_uint(st.q1.w);
+  const f3 o = mk3(st.q0), d = mk3(st.q1);
+  const float4 T4 = st.q2;
   f3 T = mk3(T4);
   int bounce = __float_as_int(T4.w);
-  uint32_t rng = st.rng;
-  const float4 h = st.hit;
+  uint32_t rng = __float_as_uint(st.q0.w);
+  const uint32_t prim = __float_as_uint(st.tp.y);
 
   bool sample_done = false;
   bool drop_acc = false;     // the sample's radiance is `add` alone (importance-sampling early return, Q8)
   f3 add = mk3(0, 0, 0);     // what this iteration adds to acc_radiance
   f3 no = o, nd = d;
 
-  if ((__float_as_uint(h.w) >> 28) == K_NONE) {  // traceRay.wgsl:12-16
+  if ((prim >> 28) == K_NONE) {  // traceRay.wgsl:12-16
     add = mk3(rc.bg[0], rc.bg[1], rc.bg[2]) * T;
     sample_done = true;
   } else {
@@ -311,7 +299,9 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
     Material m = load_material(S, mat);
     // the chunk is sorted by this class, so `bin` is wave-uniform almost everywhere
     const int bin = (m.type == 0.0f) ? BIN_LAMBERTIAN : (m.type == 1.0f) ? BIN_MIRROR : (m.type == 2.0f) ? BIN_GLASS : (m.type == 3.0f) ? BIN_ISOTROPIC : BIN_OTHER;
-    HitGeom g = resolve_hit(S, o, d, h.x, h.y, h.z, __float_as_uint(h.w));
+    float2 uv = make_float2(0.0f, 0.0f);
+    if ((prim >> 28) == K_TRI) uv = P.uv[st.slot];
+    HitGeom g = resolve_hit(S, o, d, st.tp.x, uv.x, uv.y, prim);
     f3 emission = m.emission;
     if (!g.front) emission = mk3(0, 0, 0);  // traceRay.wgsl:19-22
     float doSpecular;
@@ -423,13 +413,13 @@ constexpr int kSChunk = 512;  // slots a k_shade block sorts, shades and compact
 //      the waves are (almost) uniform in the 4-way material switch of scatterRay.wgsl; holes drop out here.  Scenes
 //      whose materials all fall into one bin skip the sort (SORT = false): only misses would diverge, and cheaply;
 //   2  shade_one per slot (state streamed in by slot); survivors' next state is staged in LDS, densely;
-//   3  the staged states are copied to the block's current OUTPUT REGION of the next queue, coalesced.  A block
-//      claims a region with one global atomic (16 or so per launch), fills it across chunks — an entry that does
-//      not fit any more continues in the next region — and marks what is left at the end as holes.
-template <bool IS, bool SORT>
+//   3  every staged survivor — dense again, all lanes busy — gets hitScene part 1 for its new ray, and state plus hit
+//      record go to the block's current OUTPUT REGION of the next queue, coalesced.  A block claims a region with one
+//      global atomic (16 or so per launch), fills it across chunks — an entry that does not fit any more continues in
+//      the next region — and marks what is left at the end as holes.
+template <bool IS, bool SORT, bool COUNT>
 __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, unsigned long long* __restrict__ totals) {
-  __shared__ float4 s_o[kSChunk], s_d[kSChunk], s_thr[kSChunk];
-  __shared__ uint32_t s_rng[kSChunk], s_pid[kSChunk];
+  __shared__ float4 s_q0[kSChunk], s_q1[kSChunk], s_q2[kSChunk];
   __shared__ uint16_t s_sorted[SORT ? kSChunk : 1];
   __shared__ uint32_t s_cnt[NUM_BINS + 2];
   __shared__ uint32_t s_nout, s_next, s_cursor, s_rend, s_b0, s_n0, s_b1;
@@ -444,6 +434,7 @@ __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, Re
     s_rend = 0;
   }
   uint32_t my_valid = 0;  // lane 0 of a wave: slots holding a path seen so far (= hitScene invocations)
+  Counters cn = {0, 0, 0, 0, 0};
   // stage one survivor per lane in LDS, densely (one LDS atomic per wave)
   auto stage = [&](bool survive, const NewState& ns) {
     const uint64_t mk = __ballot(survive);
@@ -454,11 +445,9 @@ __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, Re
       bb = (uint32_t)__shfl((int)bb, leader, 64);
       if (survive) {
         const uint32_t q = bb + lanes_below(mk);
-        s_o[q] = make_float4(ns.o.x, ns.o.y, ns.o.z, 0.0f);
-        s_d[q] = make_float4(ns.d.x, ns.d.y, ns.d.z, 0.0f);
-        s_thr[q] = make_float4(ns.T.x, ns.T.y, ns.T.z, __int_as_float(ns.bounce));
-        s_rng[q] = ns.rng;
-        s_pid[q] = ns.pid;
+        s_q0[q] = make_float4(ns.o.x, ns.o.y, ns.o.z, __uint_as_float(ns.rng));
+        s_q1[q] = make_float4(ns.d.x, ns.d.y, ns.d.z, __uint_as_float(ns.pid));
+        s_q2[q] = make_float4(ns.T.x, ns.T.y, ns.T.z, __int_as_float(ns.bounce));
       }
     }
   };
@@ -478,7 +467,7 @@ __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, Re
         const uint32_t j = (uint32_t)r * kBlock + threadIdx.x;
         int bin = -1;
         if (j < m) {
-          const uint32_t b = (P.hitmat[base + j] >> HITMAT_BIN_SHIFT) & 7u;
+          const uint32_t b = (P.hin.mat[base + j] >> HITMAT_BIN_SHIFT) & 7u;
           if (b < (uint32_t)NUM_BINS) bin = (int)b;  // 7 = hole
         }
         uint32_t rank = 0;
@@ -538,7 +527,7 @@ __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, Re
         ns.bounce = 0, ns.rng = 0, ns.pid = 0;
         if (j < m) {
           const SlotState st = load_slot(P, base + j);
-          valid = st.pid != PID_HOLE;
+          valid = __float_as_uint(st.q1.w) != PID_HOLE;
           if (valid) survive = shade_one<IS>(S, rc, P, st, L, ns);
         }
         my_valid += (uint32_t)__popcll(__ballot(valid));
@@ -577,11 +566,18 @@ __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, Re
       for (uint32_t q = threadIdx.x; q < cnt; q += kBlock) {
         if (q >= n0 && b1 == 0xffffffffu) break;
         const uint32_t dst = (q < n0) ? (b0 + q) : (b1 + (q - n0));
-        P.out.o[dst] = s_o[q];
-        P.out.d[dst] = s_d[q];
-        P.out.thr[dst] = s_thr[q];
-        P.out.rng[dst] = s_rng[q];
-        P.out.pid[dst] = s_pid[q];
+        float4 a0 = s_q0[q];
+        const float4 a1 = s_q1[q];
+        uint32_t rng = __float_as_uint(a0.w);
+        float2 tp;
+        uint32_t hm;
+        prims_for_ray<COUNT>(S, mk3(a0), mk3(a1), rng, tp, hm, cn);
+        a0.w = __uint_as_float(rng);  // hit_volume draws from the path's stream
+        P.out.q0[dst] = a0;
+        P.out.q1[dst] = a1;
+        P.out.q2[dst] = s_q2[q];
+        P.hout.tp[dst] = tp;
+        P.hout.mat[dst] = hm;
       }
     }
     __syncthreads();
@@ -589,7 +585,11 @@ __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, Re
   if (lane == 0 && my_valid) atomicAdd(&ctl->n_valid, my_valid);
   // what is left of the last region becomes holes
   __syncthreads();
-  for (uint32_t i = s_cursor + threadIdx.x; i < s_rend; i += kBlock) P.out.pid[i] = PID_HOLE;
+  for (uint32_t i = s_cursor + threadIdx.x; i < s_rend; i += kBlock) {
+    reinterpret_cast<uint32_t*>(P.out.q1 + i)[3] = PID_HOLE;
+    P.hout.mat[i] = HITMAT_HOLE;
+  }
+  if (COUNT) reduce_counters(cn, totals, false);
 }
 
 // main.wgsl:22-27 for all frame slots of the batch, in frame order; also tallies rays/paths.
@@ -631,8 +631,8 @@ struct HitOut {
 __global__ __launch_bounds__(kBlock) void k_resolve_hits(DevScene S, Paths P, uint32_t n, HitOut* __restrict__ out) {
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  float4 h = P.hit[i];
-  uint32_t prim = __float_as_uint(h.w);
+  float2 h = P.hin.tp[i];
+  uint32_t prim = __float_as_uint(h.y);
   HitOut o;
   for (int k = 0; k < 16; k++) o.material[k] = 0.0f;
   o.t = 0.0f;
@@ -640,13 +640,15 @@ __global__ __launch_bounds__(kBlock) void k_resolve_hits(DevScene S, Paths P, ui
   o.front_face = 0;
   o.hit = (prim >> 28) != K_NONE;
   if (o.hit) {
-    float4 r0 = P.in.o[i], r1 = P.in.d[i];
-    HitGeom g = resolve_hit(S, mk3(r0), mk3(r1), h.x, h.y, h.z, prim);
+    float4 r0 = P.in.q0[i], r1 = P.in.q1[i];
+    float2 uv = make_float2(0.0f, 0.0f);
+    if ((prim >> 28) == K_TRI) uv = P.uv[i];
+    HitGeom g = resolve_hit(S, mk3(r0), mk3(r1), h.x, uv.x, uv.y, prim);
     o.t = h.x;
     o.p[0] = g.p.x, o.p[1] = g.p.y, o.p[2] = g.p.z;
     o.normal[0] = g.n.x, o.normal[1] = g.n.y, o.normal[2] = g.n.z;
     o.front_face = g.front ? 1 : 0;
-    const float4* m = S.mats + 4 * (P.hitmat[i] & HITMAT_ID);
+    const float4* m = S.mats + 4 * (P.hin.mat[i] & HITMAT_ID);
     for (int k = 0; k < 4; k++) {
       float4 v = m[k];
       o.material[4 * k] = v.x, o.material[4 * k + 1] = v.y, o.material[4 * k + 2] = v.z, o.material[4 * k + 3] = v.w;
