@@ -175,6 +175,7 @@ def main():
                 "avg_launch_ms": st["bvh_ms"] / launches,
                 "launches": launches,
                 "hit_scene_algorithmic_gbs": hit_scene,
+                "work_per_ray": {k: cst[k] / max(cst["rays"], 1) for k in ("node_visits", "bvh_node_visits", "tri_tests", "quad_tests", "sphere_tests", "mat_fetches")},
                 "kernel_ms_one_step_counted_pass": {"prims": cst["prims_ms"], "bvh": cst["bvh_ms"], "shade": cst["shade_ms"], "other": cst["other_ms"], "render": cst["render_ms"]},
             },
         }

@@ -76,7 +76,6 @@ struct ptmi_ctx {
   size_t slot_cap = 0;  // slots per queue buffer (paths + room for the holes k_shade's regions leave)
   DBuf d_q0[2], d_q1[2], d_q2[2], d_tp[2], d_hm[2];  // slot-indexed live state and hit records, ping-pong
   DBuf d_uv, d_acc, d_pixsum, d_ctl, d_totals, d_scratch;
-  int traversal_mode = 0;  // 0 auto, 1 while-while, 2 flat
   int ctl_cap = 0;
 
   bool counters = false;
@@ -421,11 +420,6 @@ Paths paths_of(ptmi_ctx* c, int step, bool with_pixsum) {
 
 int stack_alloc_for(const ptmi_ctx* c) { return std::max(1, std::min(c->prm.stack_size, std::max(c->bvh_depth, 1))); }
 
-// Traversal variant.  Measured on MI355X (round 1): the flat variant (one 64-byte record fetch per lane per iteration)
-// beats while-while both on a cache-resident BVH (configs[1]: 8.95 vs 8.05 Grays/s) and on a 112 MB one
-// (configs[2]: 3.48 vs ~1.6 Grays/s), so it is the default; PTMI_TRAVERSAL=1 selects while-while for A/B runs.
-bool use_flat(const ptmi_ctx* c) { return c->traversal_mode != 1; }
-
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
@@ -445,21 +439,23 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
   ScopedSpan sp(c, T_BVH);
   const int sa = stack_alloc_for(c);
   const size_t lds = (size_t)sa * 2 * 64 * sizeof(int) + 128 * sizeof(uint32_t);  // stacks (2 words/entry) + candidate buffer
-  const bool flat = use_flat(c);
-  // VGPR budget: flat variant <= 128 VGPRs (4 waves/SIMD), while-while <= 96 (5 waves/SIMD)
-  int waves_per_cu = (int)std::min<size_t>(flat ? 16 : 20, (size_t)(160 * 1024) / (lds + 64));
+  // The abort of Q7 (hitRay.wgsl:106-109) needs sp to reach STACK_SIZE; sp never exceeds the number of inner nodes on a
+  // root-to-leaf path.  PTMI_NOABORT=0 keeps the literal stack discipline for A/B runs.
+  const bool noabort = c->bvh_depth < c->prm.stack_size && env_int("PTMI_NOABORT", 1) != 0;
+  // VGPR budget: <= 128 VGPRs (4 waves/SIMD)
+  int waves_per_cu = (int)std::min<size_t>(16, (size_t)(160 * 1024) / (lds + 64));
   if (env_int("PTMI_WAVES_PER_CU", 0) > 0) waves_per_cu = env_int("PTMI_WAVES_PER_CU", 0);  // tuning aid; 0/unset = auto
   const uint32_t want = (max_items + 63) / 64;
   const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(want, (uint32_t)c->num_cus * (uint32_t)waves_per_cu));
   const int thr = env_int("PTMI_REFILL", kRefillThreshold);
   const int leaf_batch = env_int("PTMI_LEAF_BATCH", kLeafBatch);
-#define PTMI_LAUNCH_BVH(CNT, FL) \
-  hipLaunchKernelGGL((k_bvh<CNT, FL>), dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->prm.stack_size, sa, thr, leaf_batch, tot)
+#define PTMI_LAUNCH_BVH(CNT, NA) \
+  hipLaunchKernelGGL((k_bvh<CNT, NA>), dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->prm.stack_size, sa, thr, leaf_batch, tot)
   if (c->counters) {
-    if (flat) PTMI_LAUNCH_BVH(true, true);
+    if (noabort) PTMI_LAUNCH_BVH(true, true);
     else PTMI_LAUNCH_BVH(true, false);
   } else {
-    if (flat) PTMI_LAUNCH_BVH(false, true);
+    if (noabort) PTMI_LAUNCH_BVH(false, true);
     else PTMI_LAUNCH_BVH(false, false);
   }
 #undef PTMI_LAUNCH_BVH
@@ -631,7 +627,6 @@ int ptmi_create(ptmi_ctx** out, int device_id) {
   c->device = device_id;
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   ptmi_default_params(&c->prm);
-  if (const char* tm = getenv("PTMI_TRAVERSAL")) c->traversal_mode = atoi(tm);  // 1 = while-while, 2 = flat (tuning aid)
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     delete c;

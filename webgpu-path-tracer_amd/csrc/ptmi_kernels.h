@@ -124,9 +124,9 @@ constexpr uint32_t kBvhRange = 2048;  // slots a wave claims per global atomic (
 // candidates to idle lanes: each lane runs the traversal state machine on one ray, and whenever kRefillThreshold
 // lanes have finished they are refilled, so short rays never leave lanes idle behind a long one and tails exist only
 // at kernel end.
-//   FLAT = true  one 64-byte record fetch (pair or triangle) per lane per iteration — the default.
-//   FLAT = false while-while: inner steps and triangle tests in separate loops (kept for A/B runs).
-template <bool COUNT, bool FLAT>
+// Flat traversal: one 64-byte record fetch (pair or triangle) per lane per iteration.
+//   NOABORT = the tree is shallower than STACK_SIZE (see ptmi_device.h): far children that miss outright are not pushed.
+template <bool COUNT, bool NOABORT>
 __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, StepCtl* __restrict__ ctl, int stack_size,
                                                                                        int stack_alloc, int refill_threshold, int leaf_batch,
                                                                                        unsigned long long* __restrict__ totals) {
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
     const bool more = ncand > 0 || !(exhausted && rb == re);
     const int min_working = more ? (64 - refill_threshold + 1) : 1;
     int working;
-    if (FLAT) {
+    {
       do {
         // triangle phase only when a batch of lanes waits for it, or nothing else can run
         const uint64_t pm = __ballot(has && t.pending != 0u);
@@ -230,17 +230,8 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
         if (pm && (__popcll(pm) >= leaf_batch || im == 0ull)) {
           if (has && t.pending != 0u) trav_leaf_phase<COUNT>(S, stk, t, cn);
         }
-        if (has && t.pending == 0u && t.cur < T_POP) trav_inner_phase<COUNT>(S, stack_size, stk, t, cn);
+        if (has && t.pending == 0u && t.cur < T_POP) trav_inner_phase<COUNT, NOABORT>(S, stack_size, stk, t, cn);
         working = __popcll(__ballot(has && !(t.cur == T_DONE && t.pending == 0u)));
-      } while (working >= min_working);
-    } else {
-      do {
-        while (has && t.cur != T_DONE && t.pending == 0u) trav_step<COUNT>(S, stack_size, stk, t, cn);
-        if (has && t.pending != 0u) {
-          visit_leaf<COUNT>(S, t.pending, t.o, t.d, t.orr, t.c, cn);
-          t.pending = 0u;
-        }
-        working = __popcll(__ballot(has && t.cur != T_DONE));
       } while (working >= min_working);
     }
   }
