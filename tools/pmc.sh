@@ -11,7 +11,7 @@ seen = {}
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(int)
 for f in glob.glob(out + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        k = re.sub(r'<.*', '', r['Kernel_Name']).replace('ptmi::', '').split('(')[0].strip()
+        k = r['Kernel_Name'].replace('ptmi::', '').replace('void ', '').split('(')[0].strip()
         agg[k][r['Counter_Name']] += float(r['Counter_Value'])
         n[(k, r['Counter_Name'])] += 1
         seen.setdefault((k, r['Dispatch_Id']), (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6)

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): parity tests, smoke, the four bench workloads, rocprofv3 kernel stats and the
+# FETCH_SIZE / WRITE_SIZE passes.  Everything lands in gpurun_out/rel/; tools/collect_profiles.py files it under profiles/.
+set -o pipefail
+R=gpurun_out/rel; mkdir -p $R; export TMPDIR=/tmp
+timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 | tee $R/pytest_gpu.txt || exit 1
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 | tee $R/smoke.txt || exit 1
+timeout -k 10 600 python bench.py > $R/bench_c2.json 2> $R/bench_c2.err || exit 1
+timeout -k 10 600 python bench.py --workload c3 --steps 2 > $R/bench_c3.json 2> $R/bench_c3.err || exit 1
+timeout -k 10 600 python bench.py --workload c4 --steps 1 --cpu-seconds 10 > $R/bench_c4.json 2> $R/bench_c4.err || exit 1
+timeout -k 10 600 python bench.py --workload c5 --width 3840 --height 2160 --spp 128 --steps 1 --cpu-seconds 10 > $R/bench_c5.json 2> $R/bench_c5.err || exit 1
+for w in c2 c3; do
+  extra=""; [ $w = c3 ] && extra="--spp 64"
+  rm -rf /tmp/ks_$w; (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$w -o run -- python3 $OLDPWD/bench.py --workload $w --steps 3 --warmup 1 --cpu-seconds 0 $extra > $OLDPWD/$R/ks_$w.log 2>&1) || exit 1
+  cp $(find /tmp/ks_$w -name '*kernel_stats.csv' | head -1) $R/kernel_stats_$w.csv || exit 1
+  for c in FETCH_SIZE WRITE_SIZE; do
+    tools/pmc.sh ${w}_$c $c --workload $w --steps 1 --warmup 0 --cpu-seconds 0 $extra > /dev/null || exit 1
+    cp gpurun_out/pmc_${w}_$c.json $R/
+  done
+done
+echo release pass done
