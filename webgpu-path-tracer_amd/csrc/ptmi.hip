@@ -305,13 +305,12 @@ int prepare_scene(ptmi_ctx* c) {
       float* o = &pairs[16 * (size_t)rank[i]];
       uint32_t rl = ref_of(L), rr = ref_of(R);
       int32_t axis = (int)nd[11];
-      o[0] = nl[0], o[1] = nl[1], o[2] = nl[2];
-      memcpy(&o[3], &rl, 4);
-      o[4] = nl[4], o[5] = nl[5], o[6] = nl[6];
-      memcpy(&o[7], &rr, 4);
-      o[8] = nr[0], o[9] = nr[1], o[10] = nr[2];
-      memcpy(&o[11], &axis, 4);
-      o[12] = nr[4], o[13] = nr[5], o[14] = nr[6];
+      o[0] = nl[0], o[1] = nl[1], o[2] = nl[4], o[3] = nl[5];     // L.min.xy, L.max.xy
+      o[4] = nr[0], o[5] = nr[1], o[6] = nr[4], o[7] = nr[5];     // R.min.xy, R.max.xy
+      o[8] = nl[2], o[9] = nl[6], o[10] = nr[2], o[11] = nr[6];   // L.min.z, L.max.z, R.min.z, R.max.z
+      memcpy(&o[12], &rl, 4);
+      memcpy(&o[13], &rr, 4);
+      memcpy(&o[14], &axis, 4);
       o[15] = 0.0f;
     }
     const float* rn = &c->h_bvh[0];

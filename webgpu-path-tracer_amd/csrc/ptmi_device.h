@@ -80,8 +80,9 @@ DEV float rand2D(uint32_t& s) {
 // ---- scene as the kernels see it -------------------------------------------------------------------
 // Raw arrays keep the reference's byte layout.  Two digests are derived at upload:
 //   pair64 : one 64-byte record per INNER node holding BOTH children's boxes, so that one fetch decides
-//            two box tests:  {L.min.xyz, L.ref} {L.max.xyz, R.ref} {R.min.xyz, axis} {R.max.xyz, 0}
-//            with L = node i+1, R = node right_offset(i).  A child ref is
+//            two box tests:  {L.min.xy, L.max.xy} {R.min.xy, R.max.xy} {L.min.z, L.max.z, R.min.z, R.max.z}
+//            {L.ref, R.ref, axis, 0} with L = node i+1, R = node right_offset(i) — laid out in register pairs
+//            for the packed (two floats per lane) subtract and multiply of the slab test.  A child ref is
 //              inner : index of the child's own pair record
 //              leaf  : REF_LEAF | prim_id                      (prim_count == 1, the reference's builder)
 //                      REF_LEAF | REF_MULTI | leaf_table index (any other prim_count: {prim_id, count})
@@ -433,8 +434,10 @@ DEV void visit_leaf(const DevScene& S, uint32_t ref, f3 o, f3 d, ObjRay& orr, Cl
 // entries on the measured scenes are of that kind.
 constexpr uint32_t T_DONE = 0xffffffffu, T_POP = 0xfffffffeu;
 
+typedef float v2f_t __attribute__((ext_vector_type(2)));
 struct Trav {
-  f3 o, d, inv;
+  f3 o, d;
+  v2f_t oxy, ozz, ixy, izz;  // origin and 1/dir as the pairs the packed slab arithmetic consumes ({z, z} for the z slabs)
   ObjRay orr;
   Closest c;
   uint32_t cur, pending;
@@ -512,12 +515,17 @@ template <bool COUNT, bool NOABORT>
 DEV void trav_inner_phase(const DevScene& S, int stack_size, int* __restrict__ stk, Trav& t, Counters& cn) {
   const float4* rec = S.pairs + 4 * (size_t)t.cur;
   const float4 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3v = rec[3];
-  float tsL, tbL, tsR, tbR;
-  slab(f0, f1, t.o, t.inv, tsL, tbL);
-  slab(f2, f3v, t.o, t.inv, tsR, tbR);
-  const int axis = __float_as_int(f2.w);
+  // the per-component (bound - origin) * invDir of common.wgsl:246-247, two components per instruction
+  const v2f_t l0 = (v2f_t{f0.x, f0.y} - t.oxy) * t.ixy, l1 = (v2f_t{f0.z, f0.w} - t.oxy) * t.ixy;
+  const v2f_t r0 = (v2f_t{f1.x, f1.y} - t.oxy) * t.ixy, r1 = (v2f_t{f1.z, f1.w} - t.oxy) * t.ixy;
+  const v2f_t lz = (v2f_t{f2.x, f2.y} - t.ozz) * t.izz, rz = (v2f_t{f2.z, f2.w} - t.ozz) * t.izz;
+  const float tsL = ptm_max(kTmin, ptm_max(ptm_min(l0.x, l1.x), ptm_max(ptm_min(l0.y, l1.y), ptm_min(lz.x, lz.y))));
+  const float tbL = ptm_min(ptm_max(l0.x, l1.x), ptm_min(ptm_max(l0.y, l1.y), ptm_max(lz.x, lz.y)));
+  const float tsR = ptm_max(kTmin, ptm_max(ptm_min(r0.x, r1.x), ptm_max(ptm_min(r0.y, r1.y), ptm_min(rz.x, rz.y))));
+  const float tbR = ptm_min(ptm_max(r0.x, r1.x), ptm_min(ptm_max(r0.y, r1.y), ptm_max(rz.x, rz.y)));
+  const int axis = __float_as_int(f3v.z);
   const bool neg = ((t.negmask >> axis) & 1u) != 0u;
-  const uint32_t refL = __float_as_uint(f0.w), refR = __float_as_uint(f1.w);
+  const uint32_t refL = __float_as_uint(f3v.x), refR = __float_as_uint(f3v.y);
   const uint32_t nearRef = neg ? refR : refL;
   uint32_t farRef = neg ? refL : refR;
   const float tsN = neg ? tsR : tsL, tbN = neg ? tbR : tbL;

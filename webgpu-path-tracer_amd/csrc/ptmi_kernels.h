@@ -148,7 +148,8 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
   t.pending = 0;
   t.sp = 0;
   t.negmask = 0;
-  t.o = t.d = t.inv = mk3(0, 0, 0);
+  t.o = t.d = mk3(0, 0, 0);
+  t.oxy = t.ozz = t.ixy = t.izz = v2f_t{0.0f, 0.0f};
   t.orr.mesh = -1;
   t.orr.o = t.orr.d = mk3(0, 0, 0);
   t.c.t = 0.0f, t.c.u = t.c.v = 0.0f, t.c.prim = K_NONE, t.c.mat = 0;
@@ -198,7 +199,11 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
           const uint32_t hmat = P.hin.mat[myslot] & HITMAT_WORD;
           t.o = mk3(r0);
           t.d = mk3(r1);
-          t.inv = mk3(1.0f / t.d.x, 1.0f / t.d.y, 1.0f / t.d.z);
+          t.oxy = v2f_t{t.o.x, t.o.y};
+          t.ozz = v2f_t{t.o.z, t.o.z};
+          t.ixy = v2f_t{1.0f / t.d.x, 1.0f / t.d.y};
+          t.izz.x = 1.0f / t.d.z;
+          t.izz.y = t.izz.x;
           t.negmask = (t.d.x < 0 ? 1u : 0u) | (t.d.y < 0 ? 2u : 0u) | (t.d.z < 0 ? 4u : 0u);
           t.c.t = h.x, t.c.u = 0.0f, t.c.v = 0.0f, t.c.prim = __float_as_uint(h.y);
           t.c.mat = (hmat != HITMAT_MISS) ? (int)hmat : 0;
