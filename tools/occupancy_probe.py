@@ -8,7 +8,9 @@ cam = sys.argv[2] if len(sys.argv) > 2 else "cornell"
 sc = pkg.scenes.c4_scene(n) if cam == "interior" else pkg.scenes.c3_scene(n)
 b = sc.buffers(native=pkg.ptmi.NativeHost())
 view = pkg.scenes.camera_view(*pkg.scenes.CAMERAS[cam])
-ctx = pkg.Context(0); ctx.upload_scene(b); ctx.set_params(max_bounces=8, stack_size=24); ctx.resize(1920, 1080)
+ctx = pkg.Context(0); ctx.upload_scene(b)
+stack = int(sys.argv[3]) if len(sys.argv) > 3 else 24
+ctx.set_params(max_bounces=8, stack_size=stack); ctx.resize(1920, 1080)
 for w in (8, 12, 16, 20, 24):
     os.environ["PTMI_WAVES_PER_CU"] = str(w)
     ctx.clear(); ctx.render(view, 1, 16); ctx.synchronize(); ctx.reset_stats(); ctx.set_timing(1)

@@ -75,7 +75,7 @@ struct ptmi_ctx {
   bool pixsum_alloc = false;
   size_t slot_cap = 0;  // slots per queue buffer (paths + room for the holes k_shade's regions leave)
   DBuf d_q0[2], d_q1[2], d_q2[2], d_tp[2], d_hm[2];  // slot-indexed live state and hit records, ping-pong
-  DBuf d_uv, d_acc, d_pixsum, d_ctl, d_totals, d_scratch;
+  DBuf d_uv, d_acc, d_pixsum, d_ctl, d_totals, d_scratch, d_spill;
   int ctl_cap = 0;
 
   bool counters = false;
@@ -305,12 +305,13 @@ int prepare_scene(ptmi_ctx* c) {
       float* o = &pairs[16 * (size_t)rank[i]];
       uint32_t rl = ref_of(L), rr = ref_of(R);
       int32_t axis = (int)nd[11];
-      o[0] = nl[0], o[1] = nl[1], o[2] = nl[4], o[3] = nl[5];     // L.min.xy, L.max.xy
-      o[4] = nr[0], o[5] = nr[1], o[6] = nr[4], o[7] = nr[5];     // R.min.xy, R.max.xy
-      o[8] = nl[2], o[9] = nl[6], o[10] = nr[2], o[11] = nr[6];   // L.min.z, L.max.z, R.min.z, R.max.z
-      memcpy(&o[12], &rl, 4);
-      memcpy(&o[13], &rr, 4);
-      memcpy(&o[14], &axis, 4);
+      o[0] = nl[0], o[1] = nl[1], o[2] = nl[2];
+      memcpy(&o[3], &rl, 4);
+      o[4] = nl[4], o[5] = nl[5], o[6] = nl[6];
+      memcpy(&o[7], &rr, 4);
+      o[8] = nr[0], o[9] = nr[1], o[10] = nr[2];
+      memcpy(&o[11], &axis, 4);
+      o[12] = nr[4], o[13] = nr[5], o[14] = nr[6];
       o[15] = 0.0f;
     }
     const float* rn = &c->h_bvh[0];
@@ -436,20 +437,26 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
   }
   if (c->S.n_nodes <= 0) return PTMI_OK;
   ScopedSpan sp(c, T_BVH);
+  // Stack entries per lane: the first kLdsStackEntries in LDS, the rest (rarely reached) in a per-wave spill area.
+  // 14 entries x 512 B + the candidate buffer = 7.5 KB per wave: 20 waves (5 per SIMD, the VGPR limit) fit a CU's 160 KB.
+  constexpr int kLdsStackEntries = 14;
   const int sa = stack_alloc_for(c);
-  const size_t lds = (size_t)sa * 2 * 64 * sizeof(int) + 128 * sizeof(uint32_t);  // stacks (2 words/entry) + candidate buffer
+  const int le = std::min(sa, std::max(1, env_int("PTMI_LDS_STACK", kLdsStackEntries)));
+  const int se = sa - le;
+  const size_t lds = (size_t)le * 2 * 64 * sizeof(int) + 128 * sizeof(uint32_t);  // stacks (2 words/entry) + candidate buffer
   // The abort of Q7 (hitRay.wgsl:106-109) needs sp to reach STACK_SIZE; sp never exceeds the number of inner nodes on a
   // root-to-leaf path.  PTMI_NOABORT=0 keeps the literal stack discipline for A/B runs.
   const bool noabort = c->bvh_depth < c->prm.stack_size && env_int("PTMI_NOABORT", 1) != 0;
-  // VGPR budget: <= 128 VGPRs (4 waves/SIMD)
-  int waves_per_cu = (int)std::min<size_t>(16, (size_t)(160 * 1024) / (lds + 64));
+  // VGPR budget: <= 96 VGPRs (5 waves/SIMD)
+  int waves_per_cu = (int)std::min<size_t>(20, (size_t)(160 * 1024) / (lds + 64));
   if (env_int("PTMI_WAVES_PER_CU", 0) > 0) waves_per_cu = env_int("PTMI_WAVES_PER_CU", 0);  // tuning aid; 0/unset = auto
   const uint32_t want = (max_items + 63) / 64;
   const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(want, (uint32_t)c->num_cus * (uint32_t)waves_per_cu));
+  HIP_TRY(c, c->d_spill.ensure(std::max<size_t>(16, (size_t)grid * (size_t)se * 64 * sizeof(int2))));
   const int thr = env_int("PTMI_REFILL", kRefillThreshold);
   const int leaf_batch = env_int("PTMI_LEAF_BATCH", kLeafBatch);
 #define PTMI_LAUNCH_BVH(CNT, NA) \
-  hipLaunchKernelGGL((k_bvh<CNT, NA>), dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->prm.stack_size, sa, thr, leaf_batch, tot)
+  hipLaunchKernelGGL((k_bvh<CNT, NA>), dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->prm.stack_size, le, se, c->d_spill.as<int2>(), thr, leaf_batch, tot)
   if (c->counters) {
     if (noabort) PTMI_LAUNCH_BVH(true, true);
     else PTMI_LAUNCH_BVH(true, false);
@@ -644,7 +651,7 @@ void ptmi_destroy(ptmi_ctx* c) {
   for (DBuf* b : {&c->d_spheres, &c->d_sphere_info, &c->d_quads, &c->d_quad_mat, &c->d_tris, &c->d_pretri, &c->d_meshes, &c->d_xforms,
                   &c->d_mats, &c->d_pairs, &c->d_leaf_table, &c->d_fb_own, &c->d_q0[0], &c->d_q0[1], &c->d_q1[0], &c->d_q1[1], &c->d_q2[0],
                   &c->d_q2[1], &c->d_tp[0], &c->d_tp[1], &c->d_hm[0], &c->d_hm[1], &c->d_uv, &c->d_acc, &c->d_pixsum, &c->d_ctl, &c->d_totals,
-                  &c->d_scratch})
+                  &c->d_scratch, &c->d_spill})
     b->release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;

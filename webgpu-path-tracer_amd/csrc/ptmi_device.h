@@ -80,9 +80,8 @@ DEV float rand2D(uint32_t& s) {
 // ---- scene as the kernels see it -------------------------------------------------------------------
 // Raw arrays keep the reference's byte layout.  Two digests are derived at upload:
 //   pair64 : one 64-byte record per INNER node holding BOTH children's boxes, so that one fetch decides
-//            two box tests:  {L.min.xy, L.max.xy} {R.min.xy, R.max.xy} {L.min.z, L.max.z, R.min.z, R.max.z}
-//            {L.ref, R.ref, axis, 0} with L = node i+1, R = node right_offset(i) — laid out in register pairs
-//            for the packed (two floats per lane) subtract and multiply of the slab test.  A child ref is
+//            two box tests:  {L.min.xyz, L.ref} {L.max.xyz, R.ref} {R.min.xyz, axis} {R.max.xyz, 0}
+//            with L = node i+1, R = node right_offset(i).  A child ref is
 //              inner : index of the child's own pair record
 //              leaf  : REF_LEAF | prim_id                      (prim_count == 1, the reference's builder)
 //                      REF_LEAF | REF_MULTI | leaf_table index (any other prim_count: {prim_id, count})
@@ -426,7 +425,33 @@ DEV void visit_leaf(const DevScene& S, uint32_t ref, f3 o, f3 d, ObjRay& orr, Cl
 // The traversal is a per-lane state machine so that a wave can interleave rays (lane refill):
 //   cur     = pair index of an inner node whose box has passed, T_POP (take the next stack entry) or T_DONE
 //   pending = ref of a leaf whose box has passed and whose triangles are still to be tested, 0 = none
-// `stk` is this lane's column of the LDS stack: word w of entry e lives at stk[(2e+w)*64].
+// The stack of a lane: entries 0 .. lds_entries-1 live in LDS (word w of entry e at lds[(2e+w)*64], `lds` being the
+// lane's column), deeper ones in a per-wave spill area in global memory (entry e at spill[(e-lds_entries)*64], `spill`
+// pointing at the lane's column).  Keeping at most 14 entries per lane in LDS is what lets a CU hold 20 waves (5 per
+// SIMD) on deep trees; with NOABORT hardly any ray ever has more entries than that.
+struct LaneStack {
+  int* lds;
+  int2* spill;
+  int lds_entries;
+};
+DEV void stack_write(const LaneStack& k, int e, uint32_t w0, float w1) {
+  if (e < k.lds_entries) {
+    k.lds[(2 * e) * 64] = (int)w0;
+    k.lds[(2 * e + 1) * 64] = __float_as_int(w1);
+  } else {
+    k.spill[(e - k.lds_entries) * 64] = make_int2((int)w0, __float_as_int(w1));
+  }
+}
+DEV void stack_read(const LaneStack& k, int e, uint32_t& w0, float& w1) {
+  if (e < k.lds_entries) {
+    w0 = (uint32_t)k.lds[(2 * e) * 64];
+    w1 = __int_as_float(k.lds[(2 * e + 1) * 64]);
+  } else {
+    const int2 v = k.spill[(e - k.lds_entries) * 64];
+    w0 = (uint32_t)v.x;
+    w1 = __int_as_float(v.y);
+  }
+}
 //
 // NOABORT: when the tree is shallower than STACK_SIZE the abort of Q7 cannot happen, so the stack DEPTH no longer
 // matters, only its content.  A far child whose box the ray misses outright (A = B = 0: it fails the re-test whatever
@@ -434,10 +459,8 @@ DEV void visit_leaf(const DevScene& S, uint32_t ref, f3 o, f3 d, ObjRay& orr, Cl
 // entries on the measured scenes are of that kind.
 constexpr uint32_t T_DONE = 0xffffffffu, T_POP = 0xfffffffeu;
 
-typedef float v2f_t __attribute__((ext_vector_type(2)));
 struct Trav {
-  f3 o, d;
-  v2f_t oxy, ozz, ixy, izz;  // origin and 1/dir as the pairs the packed slab arithmetic consumes ({z, z} for the z slabs)
+  f3 o, d, inv;
   ObjRay orr;
   Closest c;
   uint32_t cur, pending;
@@ -475,15 +498,16 @@ DEV void tri_record_test(const DevScene& S, int k, float4 t0, float4 t1, float4 
 // lane always has a record to fetch next.  Visit order and outcomes are those of trav_step/visit_leaf.
 // The two phases are separate functions so that the caller can run the (rarer) triangle phase only when enough
 // lanes wait for it: every phase costs its full instruction count however few lanes take part.
-DEV void trav_pop_until_pass(int* __restrict__ stk, Trav& t, Counters& cn, bool count) {
+DEV void trav_pop_until_pass(const LaneStack& stk, Trav& t, Counters& cn, bool count) {
   while (t.cur == T_POP && t.pending == 0u) {
     if (t.sp == 0) {
       t.cur = T_DONE;
       break;
     }
     t.sp--;
-    const uint32_t e = (uint32_t)stk[(2 * t.sp) * 64];
-    const float ts = __int_as_float(stk[(2 * t.sp + 1) * 64]);
+    uint32_t e;
+    float ts;
+    stack_read(stk, t.sp, e, ts);
     if (count) cn.node_visits++;
     const float ct = t.c.t;
     // isnan(ct) ? B : (A && ct > ts), written without a branch: ct > ts is false for a NaN ct
@@ -497,7 +521,7 @@ DEV void trav_pop_until_pass(int* __restrict__ stk, Trav& t, Counters& cn, bool 
 
 // lanes with a pending leaf: test its triangle(s), then pop
 template <bool COUNT>
-DEV void trav_leaf_phase(const DevScene& S, int* __restrict__ stk, Trav& t, Counters& cn) {
+DEV void trav_leaf_phase(const DevScene& S, const LaneStack& stk, Trav& t, Counters& cn) {
   if (t.pending & REF_MULTI) {  // prim_count != 1 (external BVHs): rare
     visit_leaf<COUNT>(S, t.pending, t.o, t.d, t.orr, t.c, cn);
   } else {
@@ -512,20 +536,15 @@ DEV void trav_leaf_phase(const DevScene& S, int* __restrict__ stk, Trav& t, Coun
 
 // lanes at an inner node (cur < T_POP, no pending leaf): one reference visit of its near child, far child pushed
 template <bool COUNT, bool NOABORT>
-DEV void trav_inner_phase(const DevScene& S, int stack_size, int* __restrict__ stk, Trav& t, Counters& cn) {
+DEV void trav_inner_phase(const DevScene& S, int stack_size, const LaneStack& stk, Trav& t, Counters& cn) {
   const float4* rec = S.pairs + 4 * (size_t)t.cur;
   const float4 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3v = rec[3];
-  // the per-component (bound - origin) * invDir of common.wgsl:246-247, two components per instruction
-  const v2f_t l0 = (v2f_t{f0.x, f0.y} - t.oxy) * t.ixy, l1 = (v2f_t{f0.z, f0.w} - t.oxy) * t.ixy;
-  const v2f_t r0 = (v2f_t{f1.x, f1.y} - t.oxy) * t.ixy, r1 = (v2f_t{f1.z, f1.w} - t.oxy) * t.ixy;
-  const v2f_t lz = (v2f_t{f2.x, f2.y} - t.ozz) * t.izz, rz = (v2f_t{f2.z, f2.w} - t.ozz) * t.izz;
-  const float tsL = ptm_max(kTmin, ptm_max(ptm_min(l0.x, l1.x), ptm_max(ptm_min(l0.y, l1.y), ptm_min(lz.x, lz.y))));
-  const float tbL = ptm_min(ptm_max(l0.x, l1.x), ptm_min(ptm_max(l0.y, l1.y), ptm_max(lz.x, lz.y)));
-  const float tsR = ptm_max(kTmin, ptm_max(ptm_min(r0.x, r1.x), ptm_max(ptm_min(r0.y, r1.y), ptm_min(rz.x, rz.y))));
-  const float tbR = ptm_min(ptm_max(r0.x, r1.x), ptm_min(ptm_max(r0.y, r1.y), ptm_max(rz.x, rz.y)));
-  const int axis = __float_as_int(f3v.z);
+  float tsL, tbL, tsR, tbR;
+  slab(f0, f1, t.o, t.inv, tsL, tbL);
+  slab(f2, f3v, t.o, t.inv, tsR, tbR);
+  const int axis = __float_as_int(f2.w);
   const bool neg = ((t.negmask >> axis) & 1u) != 0u;
-  const uint32_t refL = __float_as_uint(f3v.x), refR = __float_as_uint(f3v.y);
+  const uint32_t refL = __float_as_uint(f0.w), refR = __float_as_uint(f1.w);
   const uint32_t nearRef = neg ? refR : refL;
   uint32_t farRef = neg ? refL : refR;
   const float tsN = neg ? tsR : tsL, tbN = neg ? tbR : tbL;
@@ -535,15 +554,13 @@ DEV void trav_inner_phase(const DevScene& S, int stack_size, int* __restrict__ s
   farRef |= (fA ? REF_A : 0u) | (fB ? REF_B : 0u);
   if (NOABORT) {
     if (fA) {  // (B implies A)
-      stk[(2 * t.sp) * 64] = (int)farRef;
-      stk[(2 * t.sp + 1) * 64] = __float_as_int(tsF);
+      stack_write(stk, t.sp, farRef, tsF);
       t.sp++;
     } else if (COUNT) {
       cn.node_visits++;  // the pop + failed re-test the reference performs later
     }
   } else {
-    stk[(2 * t.sp) * 64] = (int)farRef;
-    stk[(2 * t.sp + 1) * 64] = __float_as_int(tsF);
+    stack_write(stk, t.sp, farRef, tsF);
     t.sp++;
     if (t.sp >= stack_size) {  // Q7
       t.cur = T_DONE;

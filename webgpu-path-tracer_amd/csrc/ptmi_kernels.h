@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DevScene S, RenderConst rc,
 #define PTMI_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(5, 8)))
 #endif
 #ifndef PTMI_BVH_ATTR
-#define PTMI_BVH_ATTR __attribute__((amdgpu_waves_per_eu(4, 8)))
+#define PTMI_BVH_ATTR __attribute__((amdgpu_waves_per_eu(5, 8)))
 #endif
 
 // Rank of this lane's entry within its material bin for the current chunk (counting sort, pass 1).
@@ -128,12 +128,16 @@ constexpr uint32_t kBvhRange = 2048;  // slots a wave claims per global atomic (
 //   NOABORT = the tree is shallower than STACK_SIZE (see ptmi_device.h): far children that miss outright are not pushed.
 template <bool COUNT, bool NOABORT>
 __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, StepCtl* __restrict__ ctl, int stack_size,
-                                                                                       int stack_alloc, int refill_threshold, int leaf_batch,
+                                                                                       int lds_entries, int spill_entries, int2* __restrict__ spill,
+                                                                                       int refill_threshold, int leaf_batch,
                                                                                        unsigned long long* __restrict__ totals) {
   extern __shared__ int lds_stack[];
   const int lane = lane_id();
-  int* stk = lds_stack + lane;
-  uint32_t* cand = reinterpret_cast<uint32_t*>(lds_stack + stack_alloc * 2 * 64);  // [128] candidate slots
+  LaneStack stk;
+  stk.lds = lds_stack + lane;
+  stk.spill = spill + (size_t)blockIdx.x * (size_t)spill_entries * 64 + lane;
+  stk.lds_entries = lds_entries;
+  uint32_t* cand = reinterpret_cast<uint32_t*>(lds_stack + lds_entries * 2 * 64);  // [128] candidate slots
   const uint32_t n = ctl->n_rays;
   // short queues (the Russian-roulette tail) are cut into smaller ranges so that they still spread over all waves
   const uint32_t range = min(kBvhRange, max(64u, ((n / (2u * gridDim.x)) + 63u) & ~63u));
@@ -148,8 +152,7 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
   t.pending = 0;
   t.sp = 0;
   t.negmask = 0;
-  t.o = t.d = mk3(0, 0, 0);
-  t.oxy = t.ozz = t.ixy = t.izz = v2f_t{0.0f, 0.0f};
+  t.o = t.d = t.inv = mk3(0, 0, 0);
   t.orr.mesh = -1;
   t.orr.o = t.orr.d = mk3(0, 0, 0);
   t.c.t = 0.0f, t.c.u = t.c.v = 0.0f, t.c.prim = K_NONE, t.c.mat = 0;
@@ -199,11 +202,7 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
           const uint32_t hmat = P.hin.mat[myslot] & HITMAT_WORD;
           t.o = mk3(r0);
           t.d = mk3(r1);
-          t.oxy = v2f_t{t.o.x, t.o.y};
-          t.ozz = v2f_t{t.o.z, t.o.z};
-          t.ixy = v2f_t{1.0f / t.d.x, 1.0f / t.d.y};
-          t.izz.x = 1.0f / t.d.z;
-          t.izz.y = t.izz.x;
+          t.inv = mk3(1.0f / t.d.x, 1.0f / t.d.y, 1.0f / t.d.z);
           t.negmask = (t.d.x < 0 ? 1u : 0u) | (t.d.y < 0 ? 2u : 0u) | (t.d.z < 0 ? 4u : 0u);
           t.c.t = h.x, t.c.u = 0.0f, t.c.v = 0.0f, t.c.prim = __float_as_uint(h.y);
           t.c.mat = (hmat != HITMAT_MISS) ? (int)hmat : 0;
