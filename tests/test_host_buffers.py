@@ -166,3 +166,22 @@ def test_native_obj_parser_matches_python_on_reference_meshes(pkg):
         a, b = ObjReader.load_model(f), nat.load_obj(f)
         for k in ("vertices", "normals"):
             assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), (f, k)
+
+
+def test_native_bvh_builder_is_thread_count_invariant(pkg, monkeypatch):
+    """The builder forks its upper levels (subtrees and the halves of the stable sort): same bytes with 1, 3 or all threads,
+    ties in the sort keys included."""
+    rng = np.random.default_rng(5)
+    n = 70000  # above the fork thresholds (4096 primitives per subtree, 32768 per sort half)
+    c = rng.uniform(-1, 1, (n, 3))
+    e = rng.uniform(0, 0.02, (n, 3))
+    bmin, bmax = c - e, c + e
+    bmin[:9000, 0] = 0.125  # many equal keys: stability decides
+    bmin[20000:26000, 2] = -0.5
+    nh = pkg.ptmi.NativeHost()
+    monkeypatch.setenv("PTMI_BUILD_THREADS", "1")
+    n1, o1 = nh.build_bvh(bmin, bmax, 2)
+    for threads in ("3", "16"):
+        monkeypatch.setenv("PTMI_BUILD_THREADS", threads)
+        n2, o2 = nh.build_bvh(bmin, bmax, 2)
+        assert np.array_equal(n1.view(np.uint32), n2.view(np.uint32)) and np.array_equal(o1, o2)

@@ -509,7 +509,7 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   const uint32_t total = rc.n_local * (uint32_t)n_frames;
   const uint32_t bound = total + total / 8 + (uint32_t)c->num_cus * 8 * 1024;  // slots a step's queue can span
   const uint32_t ew_grid = std::max<uint32_t>(1, std::min<uint32_t>((total + kBlock - 1) / kBlock, (uint32_t)c->num_cus * 16));
-  const uint32_t sgrid = std::max<uint32_t>(1, std::min<uint32_t>((bound + kSChunk - 1) / kSChunk, (uint32_t)c->num_cus * 5));
+  const uint32_t sgrid = std::max<uint32_t>(1, std::min<uint32_t>((bound + kSChunk - 1) / kSChunk, (uint32_t)c->num_cus * (uint32_t)std::max(1, env_int("PTMI_SHADE_BLOCKS_PER_CU", 5))));
   unsigned long long* tot = c->d_totals.as<unsigned long long>();
 
   // k_shade sorts its chunks by material class only when the scene has more than one (PTMI_SORT=0/1 overrides, for A/B runs)

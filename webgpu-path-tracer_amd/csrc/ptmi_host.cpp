@@ -10,6 +10,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <future>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -17,18 +19,42 @@
 
 namespace {
 
+// std::stable_sort with the upper levels of the merge tree forked: a stable sort's result is unique for a given order, so
+// halves sorted on their own threads + std::inplace_merge (stable) give exactly what one stable_sort call gives.
+template <class Cmp>
+void par_stable_sort(int64_t* first, int64_t* last, Cmp cmp, int forks) {
+  const int64_t n = last - first;
+  if (forks <= 0 || n < 32768) {
+    std::stable_sort(first, last, cmp);
+    return;
+  }
+  int64_t* mid = first + n / 2;
+  std::future<void> other;
+  bool forked = false;
+  try {
+    other = std::async(std::launch::async, [=] { par_stable_sort(first, mid, cmp, forks - 1); });
+    forked = true;
+  } catch (...) {
+  }
+  if (!forked) par_stable_sort(first, mid, cmp, forks - 1);
+  par_stable_sort(mid, last, cmp, forks - 1);
+  if (forked) other.get();
+  std::inplace_merge(first, mid, last, cmp);
+}
+
 struct Builder {
   const double* bmin;
   const double* bmax;
   int prim_type;
   float* nodes;
   int64_t* order;
-  std::vector<int64_t> tmp;
   std::vector<int64_t> left, right;
-  int64_t counter = 0;
+  int par_depth = 0;  // subtrees above this depth are built by their own threads
 
-  int64_t gen(int64_t start, int64_t end) {
-    const int64_t id = counter++;
+  // Pre-order ids need no shared counter: every leaf holds one primitive, so a subtree over k primitives has 2k-1 nodes —
+  // the left child of node `id` is id+1, the right child id + 2*(primitives on the left).  Subtrees touch disjoint rows
+  // of `nodes` and disjoint ranges of `order`, which is what lets the upper levels fork.
+  void gen(int64_t start, int64_t end, int64_t id, int depth) {
     double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};  // new AABB() (AABB.js:2-5)
     for (int64_t i = start; i <= end; i++) {
       const double* a = bmin + 3 * order[i];
@@ -54,20 +80,34 @@ struct Builder {
       row[9] = (float)(end - start + 1);
       row[11] = 0.0f;
       left[id] = right[id] = -1;
-    } else {
-      int64_t* first = order + start;
-      const double* keys = bmin;
-      std::stable_sort(first, first + span + 1, [keys, axis](int64_t a, int64_t b) { return keys[3 * a + axis] < keys[3 * b + axis]; });
-      const int64_t mid = start + span / 2;
-      const int64_t l = gen(start, mid);
-      const int64_t r = gen(mid + 1, end);
-      left[id] = l;
-      right[id] = r;
-      row[3] = (float)r;
-      row[7] = row[8] = row[9] = -1.0f;
-      row[11] = (float)axis;
+      return;
     }
-    return id;
+    int64_t* first = order + start;
+    const double* keys = bmin;
+    // the levels that cannot fork into enough subtrees yet spend their spare threads inside the sort
+    par_stable_sort(first, first + span + 1, [keys, axis](int64_t a, int64_t b) { return keys[3 * a + axis] < keys[3 * b + axis]; }, par_depth - depth);
+    const int64_t mid = start + span / 2;
+    const int64_t l = id + 1, r = id + 2 * (mid - start + 1);
+    left[id] = l;
+    right[id] = r;
+    row[3] = (float)r;
+    row[7] = row[8] = row[9] = -1.0f;
+    row[11] = (float)axis;
+    if (depth < par_depth && span >= 4096) {
+      std::future<void> other;
+      bool forked = false;
+      try {
+        other = std::async(std::launch::async, [this, start, mid, l, depth] { gen(start, mid, l, depth + 1); });
+        forked = true;
+      } catch (...) {  // no thread to be had: build it here
+      }
+      if (!forked) gen(start, mid, l, depth + 1);
+      gen(mid + 1, end, r, depth + 1);
+      if (forked) other.get();
+    } else {
+      gen(start, mid, l, depth + 1);
+      gen(mid + 1, end, r, depth + 1);
+    }
   }
 };
 
@@ -91,7 +131,15 @@ extern "C" int ptmi_build_bvh(size_t n_prims, const double* bmin, const double* 
     return PTMI_ERR_NO_MEMORY;
   }
   for (size_t i = 0; i < n_prims; i++) order_out[i] = (int64_t)i;
-  b.gen(0, (int64_t)n_prims - 1);
+  unsigned hw = std::thread::hardware_concurrency();
+  if (const char* e = getenv("PTMI_BUILD_THREADS")) hw = (unsigned)std::max(1, atoi(e));
+  hw = std::min(hw ? hw : 1u, 32u);
+  while ((1u << b.par_depth) < hw) b.par_depth++;  // 2^par_depth subtrees in flight
+  try {
+    b.gen(0, (int64_t)n_prims - 1, 0, 0);
+  } catch (...) {
+    return PTMI_ERR_NO_MEMORY;
+  }
   // populate_links (bvhNode.js:76-93): skip link = node to visit when this subtree is done or missed
   std::vector<std::pair<int64_t, int64_t>> st;
   st.emplace_back(0, -1);
