@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--stack-size", type=int, default=0)
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--frames-in-flight", type=int, default=0)
+    ap.add_argument("--bvh", default="median", choices=["median", "sah"],
+                    help="median = the reference's live builder (default, what the metric is quoted on); sah = the reference's "
+                         "other, never-called builder (lib/BVH/bvhNode.js:108-283) as an opt-in (not for c2's golden buffers)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the cpu_baseline (the 1-GPU box's CPU share)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -65,17 +68,20 @@ def main():
     if args.workload == "c5" and args.bounces == 8:
         args.bounces = 16
     spp = args.spp * world
+    sah = args.bvh == "sah"
+    if sah and args.workload == "c2":
+        raise SystemExit("--bvh sah needs a workload built through the Scene API (c3, c4, c5)")
     if args.workload == "c2":
         buffers = pkg.scenes.golden_buffers("c2")  # reference-generated buffers of configs[1] (tests/golden)
         label, stack = "configs[1]: Cornell + monkey_968.obj (967 tris)", args.stack_size or 20
     elif args.workload == "c3":
-        buffers = pkg.scenes.c3_scene().buffers(native=pkg.ptmi.NativeHost())  # procedural stand-in, 871,414 tris
+        buffers = pkg.scenes.c3_scene().buffers(native=pkg.ptmi.NativeHost(), sah=sah)  # procedural stand-in, 871,414 tris
         label, stack = "configs[2]: Cornell + dragon-class mesh (871,414 tris, procedural stand-in for stanfordDragon.obj)", args.stack_size or 24
     elif args.workload == "c4":
-        buffers = pkg.scenes.c4_scene().buffers(native=pkg.ptmi.NativeHost())
+        buffers = pkg.scenes.c4_scene().buffers(native=pkg.ptmi.NativeHost(), sah=sah)
         label, stack, cam = "configs[3]: sponza-class interior (262,267 tris, procedural stand-in for sponzaAtrium.obj), camera inside", args.stack_size or 24, "interior"
     else:
-        buffers = pkg.scenes.c5_scene().buffers(native=pkg.ptmi.NativeHost())
+        buffers = pkg.scenes.c5_scene().buffers(native=pkg.ptmi.NativeHost(), sah=sah)
         label, stack, extra = "configs[4]: Cornell + buddha-class glass mesh (1,087,716 tris, procedural stand-in for buddha.obj), importance sampling", args.stack_size or 24, dict(importance_sampling=1)
     view = pkg.scenes.camera_view(*pkg.scenes.CAMERAS[cam])
     ctx = pkg.Context(local)
@@ -158,7 +164,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s, %dx%d, %d spp per GPU (%d total), %d bounces, stack_size %d" % (label, W, H, args.spp, spp, args.bounces, stack),
+                "workload": "%s, %dx%d, %d spp per GPU (%d total), %d bounces, stack_size %d%s" % (label, W, H, args.spp, spp, args.bounces, stack, ", SAH BVH (opt-in)" if sah else ""),
                 "rays_per_step": rays_all / args.steps,
                 "mpaths_per_s": paths_all / dt_max / 1e6,
                 "parallelism": "pixel tiles x%d + 1 RCCL reduce" % world if world > 1 else "1 GPU",

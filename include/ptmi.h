@@ -174,6 +174,14 @@ int ptmi_math_eval(ptmi_ctx* ctx, int fn, size_t n, const float* x, const float*
 int ptmi_build_bvh(size_t n_prims, const double* bmin, const double* bmax, int prim_type, float* nodes_out,
                    int64_t* order_out);
 
+/* Opt-in binned-SAH build: the reference's second builder, BVH.generate_bvh_heirarchy_SAH
+ * (lib/BVH/bvhNode.js:108-283; 8 bins, leaves of any size), which the reference itself never calls —
+ * its renderer uses the median split above.  Same inputs; nodes_out must hold (2n-1) x 12 floats,
+ * *n_nodes_out receives the number of rows written.  Host threads: PTMI_BUILD_THREADS (default: all)
+ * applies to ptmi_build_bvh only. */
+int ptmi_build_bvh_sah(size_t n_prims, const double* bmin, const double* bmax, int prim_type, float* nodes_out,
+                       int64_t* order_out, size_t* n_nodes_out);
+
 /* OBJ text -> de-indexed vertex / normal arrays with the reference's accepted grammar and quirks
  * (lib/primitives/objReader.js:10-68: `v`, `vn`, `f a/b/c` triangles; tokens go through JS Number()).  The arrays are
  * malloc'ed; release them with ptmi_free.  Counts are in floats. */

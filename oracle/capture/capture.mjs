@@ -152,6 +152,33 @@ async function main() {
     await dump(tag, new Scene(), false);
   }
 
+  // ---- the reference's OTHER builder: BVH.generate_bvh_heirarchy_SAH (lib/BVH/bvhNode.js:108-283) is never called by the
+  //      reference (create_bvh -> generate_bvh_heirarchy); routing the static create_bvh to it runs that code unchanged
+  //      through the same populate_links / flattenBVH.  Pins ptmi_build_bvh_sah. ----
+  {
+    const { BVH } = await import('file://' + REF + 'lib/BVH/bvhNode.js');
+    const median = BVH.create_bvh;
+    BVH.create_bvh = (objs) => ({ bvh: BVH.generate_bvh_heirarchy_SAH(objs, 0, objs.length - 1), objs: objs });
+    for (const [tag, file, keep] of [['c2sah', 'monkey_968.obj', true], ['m5802sah', 'monkey_5802.obj', false], ['m15744sah', 'monkey_smooth_15744.obj', false]]) {
+      Scene.prototype.create_spheres = no_spheres;
+      Scene.prototype.init_mesh_data = async function () { this.mesh_data = { m: await ObjReader.load_model('./assets/' + file) }; };
+      Scene.prototype.create_meshes = function () {
+        const mat = this.add_material('dragonMat', 0, [0.0, 0.37, 0.20], [0.0, 0.95, 0.95], [0, 0, 0], 0.4, 0.3, 2.5);
+        const m = add_mesh(this, this.mesh_data['m'], mat);
+        if (keep) m.transform.update(m.transform.scale(0.6, 0.6, 0.6), m.transform.translate(0, -0.4, 0));
+        else m.transform.update(m.transform.scale(1.1, 1.1, 1.1), m.transform.rotate(Math.PI / 4, [0, 1, 0]), m.transform.translate(0.65, -0.64, 0));
+        finish_meshes.call(this);
+      };
+      const sc = new Scene();
+      await sc.init_mesh_data();
+      sc.create_meshes();
+      sc.create_bvh();
+      save(tag, 'bvh', sc.get_bvh(), keep);
+      save(tag, 'triangles', sc.get_triangles(), false);
+    }
+    BVH.create_bvh = median;
+  }
+
   // ---- cameras: mat4.targetTo exactly as lib/camera.js:32 calls it (raw JS arrays, not the f32 copies) ----
   const cams = {};
   for (const [k, eye, center, up] of [['default', [0.5, 0, 2.5], [0.5, 0, 0], [0, 1, 0]], ['cornell', [0, 0, 2.5], [0, 0, 0], [0, 1, 0]], ['oblique', [1.2, 0.4, 2.1], [0.1, -0.2, 0], [0, 1, 0]]]) {

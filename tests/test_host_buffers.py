@@ -185,3 +185,27 @@ def test_native_bvh_builder_is_thread_count_invariant(pkg, monkeypatch):
         monkeypatch.setenv("PTMI_BUILD_THREADS", threads)
         n2, o2 = nh.build_bvh(bmin, bmax, 2)
         assert np.array_equal(n1.view(np.uint32), n2.view(np.uint32)) and np.array_equal(o1, o2)
+
+
+@pytest.mark.parametrize("tag,fname,stored", [("c2sah", "monkey_968.obj", True), ("m5802sah", "monkey_5802.obj", False), ("m15744sah", "monkey_smooth_15744.obj", False)])
+def test_native_sah_builder_matches_reference_js(pkg, tag, fname, stored):
+    """ptmi_build_bvh_sah vs the reference's own BVH.generate_bvh_heirarchy_SAH (dead code in the reference, run unchanged by
+    oracle/capture/capture.mjs through the reference's populate_links / flattenBVH): byte-identical nodes and triangle order."""
+    path = os.path.join(ASSETS, fname)
+    if not os.path.exists(path):
+        pytest.skip("reference assets not present")
+    from webgpu_path_tracer_amd.host import ObjReader
+
+    man = pkg.scenes.golden_manifest()[tag]
+    data = ObjReader.load_model(path)
+    if stored:
+        sc = pkg.scenes.mesh_scene(data, scale=(0.6, 0.6, 0.6), translate=(0, -0.4, 0))
+    else:
+        sc = pkg.scenes.mesh_scene(data, scale=(1.1, 1.1, 1.1), rotate=(math.pi / 4, [0, 1, 0]), translate=(0.65, -0.64, 0))
+    b = sc.buffers(native=pkg.ptmi.NativeHost(), sah=True)
+    for k in ("bvh", "triangles"):
+        assert b[k].size == man[k]["length"], k
+        assert hashlib.sha256(np.ascontiguousarray(b[k]).tobytes()).hexdigest() == man[k]["sha256"], k
+    if stored:
+        want = np.fromfile(os.path.join(os.path.dirname(__file__), "golden", "%s_bvh.bin" % tag), np.float32)
+        assert np.array_equal(want.view(np.uint32), b["bvh"].view(np.uint32))

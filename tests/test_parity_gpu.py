@@ -335,3 +335,27 @@ def test_reference_default_max_bounces_100(ctx, pkg, oracle):
     want, ost = oracle.render(b, 160, 100, cornell_view(pkg), 1, 2)
     assert_same_bits(got, want, "c2, 100 bounces")
     assert st["rays"] == ost["rays"] and st["intersect_launches"] < 100  # early exit happened
+
+
+def test_sah_bvh_bit_exact(ctx, pkg, oracle):
+    """The opt-in SAH builder's trees (deeper, leaves of 1-2 triangles) through the same kernels: both the NOABORT path
+    (stack 64 > depth) and the literal stack discipline with the Q7 abort live (stack 20), incl. stack entries beyond the
+    14 kept in LDS."""
+    b = pkg.scenes.c4_scene(40000).buffers(native=pkg.ptmi.NativeHost(), sah=True)
+    nodes = b["bvh"].reshape(-1, 12)
+    assert (nodes[nodes[:, 7] == 2][:, 9] > 1).any()  # multi-triangle leaves are present
+    ctx.upload_scene(b)
+    view = cornell_view(pkg, "interior")
+    for stack in (64, 20):
+        ctx.set_params(max_bounces=6, stack_size=stack)
+        ctx.resize(192, 108)
+        ctx.reset_stats()
+        ctx.set_counters(True)
+        ctx.render(view, 1, 2)
+        got = ctx.read_framebuffer()
+        st = ctx.stats()
+        ctx.set_counters(False)
+        want, ost = oracle.render(b, 192, 108, view, 1, 2, max_bounces=6, stack_size=stack)
+        assert_same_bits(got, want, "sah stack %d" % stack)
+        for k in ("rays", "node_visits", "tri_tests", "quad_tests", "mat_fetches"):
+            assert st[k] == ost[k], (stack, k)

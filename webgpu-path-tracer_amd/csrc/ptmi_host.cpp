@@ -156,6 +156,196 @@ extern "C" int ptmi_build_bvh(size_t n_prims, const double* bmin, const double* 
 }
 
 
+// ---- binned-SAH builder, opt-in --------------------------------------------------------------------------------------
+// Restates the reference's SECOND builder, BVH.generate_bvh_heirarchy_SAH (lib/BVH/bvhNode.js:108-283: 8 bins per axis,
+// 7 candidate planes, leaf when the best split costs no less than the node; leaves hold any number of primitives).  The
+// reference never calls it (create_bvh uses the median split), so the renderer's default stays the median builder; this
+// one is for users who want the ~2x cheaper traversal the reference's own benchmarks.txt shows for SAH trees.  Output is
+// byte-identical to running that method through the reference's flattening (tests/golden/*sah*).
+namespace {
+
+struct Box {
+  double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};  // new AABB()
+  void merge(const double* a, const double* b) {                      // AABB.merge: min(a.min, this.min) ...
+    for (int k = 0; k < 3; k++) {
+      lo[k] = std::min(a[k], lo[k]);
+      hi[k] = std::max(b[k], hi[k]);
+    }
+  }
+  void merge(const Box& o) { merge(o.lo, o.hi); }
+  double area() const {  // AABB.surface_area
+    const double e0 = hi[0] - lo[0], e1 = hi[1] - lo[1], e2 = hi[2] - lo[2];
+    return e0 * e1 + e1 * e2 + e2 * e0;
+  }
+};
+
+struct SahNode {
+  Box box;
+  int64_t start = 0, end = 0, left = -1, right = -1;
+  int axis = 0;
+  bool leaf = false;
+};
+
+struct SahBuilder {
+  const double* bmin;
+  const double* bmax;
+  int64_t* order;
+  std::vector<SahNode> nodes;
+
+  double centroid(int64_t prim, int a) const { return (bmin[3 * prim + a] + bmax[3 * prim + a]) / 2; }
+
+  // BVH.FindBestSplitPlane (bvhNode.js:221-283)
+  void best_split(int64_t start, int64_t end, int& axis, double& split_pos, double& best_cost) const {
+    best_cost = 1e30;
+    axis = 0;
+    split_pos = 0;
+    constexpr int BINS = 8;
+    for (int a = 0; a < 3; a++) {
+      double bounds_min = 1e30, bounds_max = -1e30;
+      for (int64_t i = start; i <= end; i++) {
+        const double c = centroid(order[i], a);
+        bounds_min = std::min(bounds_min, c);
+        bounds_max = std::max(bounds_max, c);
+      }
+      if (bounds_min == bounds_max) continue;
+      Box bin_box[BINS];
+      double bin_count[BINS] = {0, 0, 0, 0, 0, 0, 0, 0};
+      double scale = BINS / (bounds_max - bounds_min);
+      for (int64_t i = start; i <= end; i++) {
+        const int64_t p = order[i];
+        const double f = std::floor((centroid(p, a) - bounds_min) * scale);
+        const int b = (int)std::min((double)(BINS - 1), f);
+        bin_count[b] += 1;
+        bin_box[b].merge(bmin + 3 * p, bmax + 3 * p);
+      }
+      double left_area[BINS - 1], right_area[BINS - 1], left_count[BINS - 1], right_count[BINS - 1];
+      Box lbox, rbox;
+      double lsum = 0, rsum = 0;
+      for (int i = 0; i < BINS - 1; i++) {
+        lsum += bin_count[i];
+        left_count[i] = lsum;
+        lbox.merge(bin_box[i]);
+        left_area[i] = lbox.area();
+        rsum += bin_count[BINS - 1 - i];
+        right_count[BINS - 2 - i] = rsum;
+        rbox.merge(bin_box[BINS - 1 - i]);
+        right_area[BINS - 2 - i] = rbox.area();
+      }
+      scale = (bounds_max - bounds_min) / BINS;
+      for (int i = 0; i < BINS - 1; i++) {
+        const double cost = left_count[i] * left_area[i] + right_count[i] * right_area[i];
+        if (cost < best_cost) {
+          axis = a;
+          split_pos = bounds_min + scale * (i + 1);
+          best_cost = cost;
+        }
+      }
+    }
+  }
+
+  // generate_bvh_heirarchy_SAH (bvhNode.js:108-202); an explicit stack as there: SAH trees can be very deep
+  void build(int64_t n) {
+    nodes.clear();
+    nodes.emplace_back();
+    nodes[0].start = 0;
+    nodes[0].end = n - 1;
+    std::vector<int64_t> todo{0};
+    while (!todo.empty()) {
+      const int64_t id = todo.back();
+      todo.pop_back();
+      const int64_t start = nodes[id].start, end = nodes[id].end;
+      Box box;
+      for (int64_t i = start; i <= end; i++) box.merge(bmin + 3 * order[i], bmax + 3 * order[i]);
+      nodes[id].box = box;  // (the reference re-merges it from the children on the way back: the same union)
+      const double parent_cost = (double)(end - start + 1) * box.area();
+      int axis;
+      double split_pos, best_cost;
+      best_split(start, end, axis, split_pos, best_cost);
+      if (best_cost >= parent_cost) {
+        nodes[id].leaf = true;
+        continue;
+      }
+      const double* keys = bmin;
+      std::stable_sort(order + start, order + end + 1, [keys, axis](int64_t a, int64_t b) { return keys[3 * a + axis] < keys[3 * b + axis]; });
+      int64_t split = start;
+      while (split < end - 1) {
+        if (centroid(order[split], axis) <= split_pos) split++;
+        else break;
+      }
+      const int64_t l = (int64_t)nodes.size(), r = l + 1;
+      nodes.emplace_back();
+      nodes.emplace_back();
+      nodes[l].start = start, nodes[l].end = split;
+      nodes[r].start = split + 1, nodes[r].end = end;
+      nodes[id].left = l, nodes[id].right = r, nodes[id].axis = axis;
+      todo.push_back(r);
+      todo.push_back(l);
+    }
+  }
+};
+
+}  // namespace
+
+extern "C" int ptmi_build_bvh_sah(size_t n_prims, const double* bmin, const double* bmax, int prim_type, float* nodes_out, int64_t* order_out,
+                                  size_t* n_nodes_out) {
+  if (!n_nodes_out) return PTMI_ERR_INVALID_ARG;
+  *n_nodes_out = 0;
+  if (n_prims == 0) return PTMI_OK;
+  if (!bmin || !bmax || !nodes_out || !order_out) return PTMI_ERR_INVALID_ARG;
+  if (n_prims > (size_t)1 << 27) return PTMI_ERR_UNSUPPORTED;
+  try {
+    SahBuilder b;
+    b.bmin = bmin, b.bmax = bmax, b.order = order_out;
+    for (size_t i = 0; i < n_prims; i++) order_out[i] = (int64_t)i;
+    b.build((int64_t)n_prims);
+    // flattenBVH (bvhBuilder.js:37-54): pre-order ids; populate_links (bvhNode.js:76-93): the skip link
+    const size_t nn = b.nodes.size();
+    std::vector<int64_t> flat_id(nn, -1);
+    struct Item {
+      int64_t node, next;
+    };
+    std::vector<Item> st{{0, -1}};
+    std::vector<int64_t> pre;  // tree node of each flat row, in order
+    pre.reserve(nn);
+    std::vector<int64_t> next_of(nn, -1);
+    while (!st.empty()) {
+      const Item it = st.back();
+      st.pop_back();
+      flat_id[it.node] = (int64_t)pre.size();
+      pre.push_back(it.node);
+      next_of[it.node] = it.next;
+      const SahNode& nd = b.nodes[it.node];
+      if (!nd.leaf) {
+        st.push_back({nd.right, it.next});
+        st.push_back({nd.left, nd.right});
+      }
+    }
+    for (size_t k = 0; k < pre.size(); k++) {
+      const SahNode& nd = b.nodes[pre[k]];
+      float* row = nodes_out + 12 * k;
+      row[0] = (float)nd.box.lo[0], row[1] = (float)nd.box.lo[1], row[2] = (float)nd.box.lo[2];
+      row[4] = (float)nd.box.hi[0], row[5] = (float)nd.box.hi[1], row[6] = (float)nd.box.hi[2];
+      row[10] = next_of[pre[k]] < 0 ? -1.0f : (float)flat_id[next_of[pre[k]]];
+      if (nd.leaf) {
+        row[3] = -1.0f;
+        row[7] = (float)prim_type;
+        row[8] = (float)nd.start;
+        row[9] = (float)(nd.end - nd.start + 1);
+        row[11] = 0.0f;
+      } else {
+        row[3] = (float)flat_id[nd.right];
+        row[7] = row[8] = row[9] = -1.0f;
+        row[11] = (float)nd.axis;
+      }
+    }
+    *n_nodes_out = pre.size();
+  } catch (...) {
+    return PTMI_ERR_NO_MEMORY;
+  }
+  return PTMI_OK;
+}
+
+
 // ---- OBJ parsing with the reference's grammar (lib/primitives/objReader.js:10-68) ---------------------------------
 namespace {
 

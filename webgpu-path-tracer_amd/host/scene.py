@@ -328,12 +328,19 @@ class Scene:
         self.material_id += 1
         return self.material_id - 1
 
-    def create_bvh(self, native=None):  # lib/scene.js:253-259
+    def create_bvh(self, native=None, sah=False):  # lib/scene.js:253-259
+        """sah=True swaps in the reference's other builder (BVH.generate_bvh_heirarchy_SAH, bvhNode.js:108-283 — dead
+        code there; native only): an opt-in, the reference's renderer always uses the median split."""
         if not self.meshes:
             return
         bmin = np.concatenate([m.bmin for m in self.meshes])
         bmax = np.concatenate([m.bmax for m in self.meshes])
-        self.bvh_array, order = build_bvh(bmin, bmax, 2, native=native)
+        if sah:
+            if native is None:
+                raise ValueError("the SAH builder exists in native code only: pass native=NativeHost()")
+            self.bvh_array, order = native.build_bvh_sah(bmin, bmax, 2)
+        else:
+            self.bvh_array, order = build_bvh(bmin, bmax, 2, native=native)
         self.tri_data = self.tri_data[order]
 
     def get_bvh(self):
@@ -362,7 +369,7 @@ class Scene:
             return np.zeros(0, np.float32)
         return np.concatenate([o.transform.getTransform() for o in self.objs]).astype(np.float32)
 
-    def buffers(self, native=None):
+    def buffers(self, native=None, sah=False):
         """The renderer.js:78-87 call order, returning the seven uploadable arrays."""
         self.init_mesh_data()
         self.create_meshes()
@@ -373,7 +380,7 @@ class Scene:
             "materials": self.get_materials(),
             "transforms": self.get_transforms(),
         }
-        self.create_bvh(native=native)
+        self.create_bvh(native=native, sah=sah)
         out["bvh"] = self.get_bvh()
         out["triangles"] = self.get_triangles()
         return out

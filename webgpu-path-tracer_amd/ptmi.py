@@ -18,7 +18,7 @@ SYMBOLS = [
     "ptmi_render_frame", "ptmi_render", "ptmi_synchronize", "ptmi_read_framebuffer", "ptmi_write_framebuffer",
     "ptmi_framebuffer_device_ptr", "ptmi_bind_framebuffer", "ptmi_stream", "ptmi_resolve_rgba8", "ptmi_set_counters",
     "ptmi_set_timing", "ptmi_get_stats", "ptmi_reset_stats", "ptmi_trace", "ptmi_math_eval", "ptmi_build_bvh",
-    "ptmi_obj_parse", "ptmi_free",
+    "ptmi_build_bvh_sah", "ptmi_obj_parse", "ptmi_free",
 ]
 
 
@@ -99,6 +99,7 @@ def load_library(build=False):
     L.ptmi_trace.argtypes = [vp, sz, fp, fp, fp]
     L.ptmi_math_eval.argtypes = [vp, i32, sz, fp, fp, fp]
     L.ptmi_build_bvh.argtypes = [sz, fp, fp, i32, fp, fp]
+    L.ptmi_build_bvh_sah.argtypes = [sz, fp, fp, i32, fp, fp, ctypes.POINTER(sz)]
     L.ptmi_obj_parse.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(vp), ctypes.POINTER(sz)]
     L.ptmi_free.argtypes = [vp]
     L.ptmi_free.restype = None
@@ -138,6 +139,19 @@ class NativeHost:
             raise PtmiError(st, "ptmi_build_bvh failed")
         return nodes, order
 
+
+    def build_bvh_sah(self, bmin, bmax, prim_type=2):
+        """The reference's binned-SAH builder (lib/BVH/bvhNode.js:108-283, dead code there), opt-in."""
+        bmin = np.ascontiguousarray(bmin, np.float64)
+        bmax = np.ascontiguousarray(bmax, np.float64)
+        n = bmin.shape[0]
+        nodes = np.zeros((max(2 * n - 1, 0), 12), np.float32)
+        order = np.zeros(n, np.int64)
+        count = ctypes.c_size_t()
+        st = self.lib.ptmi_build_bvh_sah(n, _ptr(bmin), _ptr(bmax), prim_type, _ptr(nodes), _ptr(order), ctypes.byref(count))
+        if st != 0:
+            raise PtmiError(st, "ptmi_build_bvh_sah failed")
+        return nodes[: count.value].copy(), order
 
     def parse_obj(self, text):
         """ObjReader.parse in native code: {vertices, normals} float32 arrays (lib/primitives/objReader.js grammar)."""
