@@ -46,7 +46,7 @@ def test_js_scene_code_matches_reference_buffers():
     rep = json.loads(out)
     assert len(rep) >= 17 and all(rep.values()), [k for k, v in rep.items() if not v]
     if os.path.isdir(assets):
-        assert len(rep) == 48
+        assert len(rep) == 49
 
 
 @needs_node

@@ -26,6 +26,13 @@ async function check(tag, make) {
     await check('c2', () => c2Scene(obj('monkey_968.obj')));
     await check('c2m', () => c2mScene(obj('icosphere.obj'), obj('cube.obj')));
   }
+  if (assets && fs.existsSync(path.join(assets, 'monkey_968.obj'))) {   // the opt-in SAH builder through the addon
+    const sc = c2Scene(obj('monkey_968.obj'));
+    sc.native = loadNative();
+    sc.useSAH = true;
+    const b = await sceneBuffers(sc);
+    report['c2sah.bvh.native'] = same(b.bvh, rd(path.join(golden, 'c2sah_bvh.bin')));
+  }
   if (assets && fs.existsSync(path.join(assets, 'monkey_968.obj'))) {
     for (const f of ['cube.obj', 'monkey_968.obj', 'hole.obj']) {
       const text = fs.readFileSync(path.join(assets, f), 'utf8');

@@ -198,7 +198,9 @@ export class Scene {   // lib/scene.js surface; subclasses or callers fill creat
     const bmin = new Float64Array(3 * total), bmax = new Float64Array(3 * total);
     let o = 0;
     for (const m of this.meshes) { bmin.set(m.bmin, o); bmax.set(m.bmax, o); o += m.bmin.length; }
-    const r = build_bvh(bmin, bmax, 2, this.native);
+    // this.useSAH (opt-in, native only): the reference's other builder, BVH.generate_bvh_heirarchy_SAH (bvhNode.js:108-283)
+    if (this.useSAH && !this.native) throw new Error('useSAH needs the native host (scene.native = loadNative())');
+    const r = this.useSAH ? this.native.buildBVHSAH(bmin, bmax, 2) : build_bvh(bmin, bmax, 2, this.native);
     this.bvh_array = r.nodes;
     const sorted = new Float32Array(this.tri_data.length);
     for (let k = 0; k < total; k++) sorted.set(this.tri_data.subarray(r.order[k] * 24, r.order[k] * 24 + 24), k * 24);
