@@ -1,0 +1,14 @@
+#!/bin/bash
+# usage: tools/trace_kernel.sh <tag> <kernel substring> <bench args...> — per-launch durations (ms) of one kernel, timed pass only
+tag=$1; kern=$2; shift 2
+out=/tmp/kt_$tag; rm -rf $out; export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out -o run -- python3 bench.py "$@" > /dev/null 2>&1
+python3 - "$out" "$kern" <<'PY'
+import csv, glob, sys
+rows = []
+for f in glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        if sys.argv[2] in r['Kernel_Name']: rows.append((int(r['Start_Timestamp']), (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6, r['Kernel_Name'][:40]))
+rows.sort()
+print(' '.join('%.2f' % d for _, d, _ in rows)); print('sum %.1f ms over %d launches' % (sum(d for _, d, _ in rows), len(rows)))
+PY

@@ -75,7 +75,7 @@ struct ptmi_ctx {
   bool pixsum_alloc = false;
   size_t slot_cap = 0;  // slots per queue buffer (paths + room for the holes k_shade's regions leave)
   DBuf d_q0[2], d_q1[2], d_q2[2], d_tp[2], d_hm[2];  // slot-indexed live state and hit records, ping-pong
-  DBuf d_uv, d_acc, d_pixsum, d_ctl, d_totals, d_scratch, d_spill;
+  DBuf d_uv, d_acc, d_pixsum, d_ctl, d_totals, d_scratch, d_spill, d_heads;
   int ctl_cap = 0;
 
   bool counters = false;
@@ -452,11 +452,16 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
   if (env_int("PTMI_WAVES_PER_CU", 0) > 0) waves_per_cu = env_int("PTMI_WAVES_PER_CU", 0);  // tuning aid; 0/unset = auto
   const uint32_t want = (max_items + 63) / 64;
   const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(want, (uint32_t)c->num_cus * (uint32_t)waves_per_cu));
+  // Range claims go through 16 team counters (128 B apart) instead of one: a launch makes tens of thousands of claims and
+  // same-address global atomics serialise at ~11 ns each (configs[1]: +2 %).
+  const uint32_t n_teams = std::max<uint32_t>(1, std::min<uint32_t>(kMaxTeams, (uint32_t)env_int("PTMI_BVH_TEAMS", 16)));
+  HIP_TRY(c, c->d_heads.ensure(kMaxTeams * kHeadStride * sizeof(uint32_t)));
+  HIP_TRY(c, hipMemsetAsync(c->d_heads.p, 0, kMaxTeams * kHeadStride * sizeof(uint32_t), c->stream));
   HIP_TRY(c, c->d_spill.ensure(std::max<size_t>(16, (size_t)grid * (size_t)se * 64 * sizeof(int2))));
   const int thr = env_int("PTMI_REFILL", kRefillThreshold);
   const int leaf_batch = env_int("PTMI_LEAF_BATCH", kLeafBatch);
 #define PTMI_LAUNCH_BVH(CNT, NA) \
-  hipLaunchKernelGGL((k_bvh<CNT, NA>), dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->prm.stack_size, le, se, c->d_spill.as<int2>(), thr, leaf_batch, tot)
+  hipLaunchKernelGGL((k_bvh<CNT, NA>), dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), n_teams, c->prm.stack_size, le, se, c->d_spill.as<int2>(), thr, leaf_batch, tot)
   if (c->counters) {
     if (noabort) PTMI_LAUNCH_BVH(true, true);
     else PTMI_LAUNCH_BVH(true, false);
@@ -651,7 +656,7 @@ void ptmi_destroy(ptmi_ctx* c) {
   for (DBuf* b : {&c->d_spheres, &c->d_sphere_info, &c->d_quads, &c->d_quad_mat, &c->d_tris, &c->d_pretri, &c->d_meshes, &c->d_xforms,
                   &c->d_mats, &c->d_pairs, &c->d_leaf_table, &c->d_fb_own, &c->d_q0[0], &c->d_q0[1], &c->d_q1[0], &c->d_q1[1], &c->d_q2[0],
                   &c->d_q2[1], &c->d_tp[0], &c->d_tp[1], &c->d_hm[0], &c->d_hm[1], &c->d_uv, &c->d_acc, &c->d_pixsum, &c->d_ctl, &c->d_totals,
-                  &c->d_scratch, &c->d_spill})
+                  &c->d_scratch, &c->d_spill, &c->d_heads})
     b->release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;

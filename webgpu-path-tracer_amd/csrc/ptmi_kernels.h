@@ -116,6 +116,7 @@ constexpr int kRefillThreshold = 16;
 // The triangle phase of the flat traversal runs once this many lanes hold a pending leaf (or nothing else can run).
 constexpr int kLeafBatch = 16;
 constexpr uint32_t kBvhRange = 2048;  // slots a wave claims per global atomic (less when the queue is short)
+constexpr uint32_t kHeadStride = 32, kMaxTeams = 64;  // k_bvh's claim counters: one per team of waves, 128 bytes apart
 
 // hitScene, part 2 (hitRay.wgsl:42-110): BVH traversal by persistent, barrier-free waves.
 // One block = one wave, so LDS (the traversal stacks, stack_alloc x 512 B per wave, plus a 64-entry candidate
@@ -127,7 +128,7 @@ constexpr uint32_t kBvhRange = 2048;  // slots a wave claims per global atomic (
 // Flat traversal: one 64-byte record fetch (pair or triangle) per lane per iteration.
 //   NOABORT = the tree is shallower than STACK_SIZE (see ptmi_device.h): far children that miss outright are not pushed.
 template <bool COUNT, bool NOABORT>
-__global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, StepCtl* __restrict__ ctl, int stack_size,
+__global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads, uint32_t n_teams, int stack_size,
                                                                                        int lds_entries, int spill_entries, int2* __restrict__ spill,
                                                                                        int refill_threshold, int leaf_batch,
                                                                                        unsigned long long* __restrict__ totals) {
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
   const uint32_t n = ctl->n_rays;
   // short queues (the Russian-roulette tail) are cut into smaller ranges so that they still spread over all waves
   const uint32_t range = min(kBvhRange, max(64u, ((n / (2u * gridDim.x)) + 63u) & ~63u));
+  const uint32_t team = blockIdx.x % n_teams;
   Counters cn = {0, 0, 0, 0, 0};
   uint32_t rb = 0, re = 0;   // this wave's claimed range of slots still to be scanned (wave-uniform)
   uint32_t ncand = 0;        // candidates waiting in `cand` (wave-uniform)
@@ -174,13 +176,17 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
       // top up the candidate buffer: scan 64 slots at a time until it holds enough or the queue is exhausted
       while (ncand < want && !(exhausted && rb == re)) {
         if (rb == re) {  // claim the next range of slots
-          uint32_t nb = 0;
-          if (lane == 0) nb = atomicAdd(&ctl->head_b, range);
-          nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
-          if (nb >= n) {
+          // range r belongs to team r % n_teams; the waves of a team (every n_teams-th wave) share that team's counter:
+          // one counter for everybody means tens of thousands of same-address atomics per launch at ~11 ns each
+          uint32_t i = 0;
+          if (lane == 0) i = atomicAdd(&heads[team * kHeadStride], 1u);
+          i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+          const uint64_t nb64 = ((uint64_t)team + (uint64_t)n_teams * i) * range;
+          if (nb64 >= (uint64_t)n) {
             exhausted = true;
             continue;
           }
+          const uint32_t nb = (uint32_t)nb64;
           rb = nb;
           re = min(nb + range, n);
         }
