@@ -183,14 +183,13 @@ int prepare_scene(ptmi_ctx* c) {
   }
   // material word = id | shade bin << 28 (ptmi_device.h)
   std::vector<int32_t> mat_word((size_t)n_mat);
-  uint32_t classes = 0;
+  uint32_t classes = 0;  // shade bins of the materials some primitive actually refers to (the table may hold unused ones)
   for (int i = 0; i < n_mat; i++) {
     float ty = c->h_mats[16 * (size_t)i + 14];
     int bin = (ty == 0.0f) ? BIN_LAMBERTIAN : (ty == 1.0f) ? BIN_MIRROR : (ty == 2.0f) ? BIN_GLASS : (ty == 3.0f) ? BIN_ISOTROPIC : BIN_OTHER;
     mat_word[i] = i | (bin << HITMAT_BIN_SHIFT);
-    classes |= 1u << bin;
   }
-  c->material_classes = __builtin_popcount(classes);
+  auto use_class = [&](int m) { classes |= 1u << ((uint32_t)mat_word[m] >> HITMAT_BIN_SHIFT); };
   if (n_mat >= (1 << HITMAT_BIN_SHIFT)) return fail(c, PTMI_ERR_UNSUPPORTED, "more than 2^28 materials");
   std::vector<int32_t> sphere_info(2 * (size_t)n_sph), quad_mat((size_t)n_quad);
   for (int i = 0; i < n_sph; i++) {
@@ -201,6 +200,7 @@ int prepare_scene(ptmi_ctx* c) {
     }
     float medium = c->h_mats[16 * (size_t)m + 14];
     sphere_info[2 * (size_t)i] = mat_word[m];
+    use_class(m);
     sphere_info[2 * (size_t)i + 1] = (medium < 3.0f) ? 0 : 1;  // hitRay.wgsl:8-9
   }
   int light = -1;
@@ -211,6 +211,7 @@ int prepare_scene(ptmi_ctx* c) {
       return fail(c, PTMI_ERR_BAD_SCENE, msg);
     }
     quad_mat[i] = mat_word[m];
+    use_class(m);
     if (light < 0 && c->h_mats[16 * (size_t)m + 8] > 0.0f) light = i;  // common.wgsl:258-269
   }
   for (int i = 0; i < n_mesh; i++) {
@@ -219,7 +220,9 @@ int prepare_scene(ptmi_ctx* c) {
       snprintf(msg, sizeof msg, "mesh %d: global_id %d / material_id %d out of range (transforms %d, materials %d)", i, me[2], me[3], n_xf, n_mat);
       return fail(c, PTMI_ERR_BAD_SCENE, msg);
     }
+    use_class(me[3]);
   }
+  c->material_classes = __builtin_popcount(classes);
   // pretri digest: same f32 operations the shader performs per test (common.wgsl:199-201)
   std::vector<float> pretri(16 * (size_t)n_tri);
   for (int i = 0; i < n_tri; i++) {
