@@ -399,6 +399,7 @@ int ensure_paths(ptmi_ctx* c, size_t npaths, int n_ctl, bool need_pixsum) {
     HIP_TRY(c, c->d_ctl.ensure((size_t)n_ctl * sizeof(StepCtl)));
     c->ctl_cap = n_ctl;
   }
+  HIP_TRY(c, c->d_heads.ensure(kMaxTeams * kHeadStride * sizeof(uint32_t)));
   if (!c->d_totals.p) {
     HIP_TRY(c, c->d_totals.ensure(16 * sizeof(unsigned long long)));
     HIP_TRY(c, hipMemsetAsync(c->d_totals.p, 0, 16 * sizeof(unsigned long long), c->stream));
@@ -435,8 +436,8 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
   const uint32_t pgrid = std::max<uint32_t>(1, std::min<uint32_t>((max_items + kBlock - 1) / kBlock, (uint32_t)c->num_cus * 32));
   if (with_prims) {
     ScopedSpan sp(c, T_PRIMS);
-    if (c->counters) hipLaunchKernelGGL(k_prims<true>, dim3(pgrid), dim3(kBlock), 0, c->stream, c->S, P, ctl, tot);
-    else hipLaunchKernelGGL(k_prims<false>, dim3(pgrid), dim3(kBlock), 0, c->stream, c->S, P, ctl, tot);
+    if (c->counters) hipLaunchKernelGGL(k_prims<true>, dim3(pgrid), dim3(kBlock), 0, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), tot);
+    else hipLaunchKernelGGL(k_prims<false>, dim3(pgrid), dim3(kBlock), 0, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), tot);
   }
   if (c->S.n_nodes <= 0) return PTMI_OK;
   ScopedSpan sp(c, T_BVH);
@@ -458,8 +459,7 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
   // Range claims go through 16 team counters (128 B apart) instead of one: a launch makes tens of thousands of claims and
   // same-address global atomics serialise at ~11 ns each (configs[1]: +2 %).
   const uint32_t n_teams = std::max<uint32_t>(1, std::min<uint32_t>(kMaxTeams, (uint32_t)env_int("PTMI_BVH_TEAMS", 16)));
-  HIP_TRY(c, c->d_heads.ensure(kMaxTeams * kHeadStride * sizeof(uint32_t)));
-  HIP_TRY(c, hipMemsetAsync(c->d_heads.p, 0, kMaxTeams * kHeadStride * sizeof(uint32_t), c->stream));
+  // (the counters are zeroed by the kernel that filled this queue)
   HIP_TRY(c, c->d_spill.ensure(std::max<size_t>(16, (size_t)grid * (size_t)se * 64 * sizeof(int2))));
   const int thr = env_int("PTMI_REFILL", kRefillThreshold);
   const int leaf_batch = env_int("PTMI_LEAF_BATCH", kLeafBatch);
@@ -528,8 +528,8 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   {
     ScopedSpan s(c, T_OTHER);
     HIP_TRY(c, hipMemsetAsync(ctl, 0, (size_t)(n_steps + 2) * sizeof(StepCtl), c->stream));
-    if (c->counters) hipLaunchKernelGGL(k_generate<true>, dim3(ew_grid), dim3(kBlock), 0, c->stream, c->S, rc, paths_of(c, 0, rc.num_samples > 1), ctl, tot);
-    else hipLaunchKernelGGL(k_generate<false>, dim3(ew_grid), dim3(kBlock), 0, c->stream, c->S, rc, paths_of(c, 0, rc.num_samples > 1), ctl, tot);
+    if (c->counters) hipLaunchKernelGGL(k_generate<true>, dim3(ew_grid), dim3(kBlock), 0, c->stream, c->S, rc, paths_of(c, 0, rc.num_samples > 1), ctl, c->d_heads.as<uint32_t>(), tot);
+    else hipLaunchKernelGGL(k_generate<false>, dim3(ew_grid), dim3(kBlock), 0, c->stream, c->S, rc, paths_of(c, 0, rc.num_samples > 1), ctl, c->d_heads.as<uint32_t>(), tot);
   }
   for (int s = 0; s < n_steps; s++) {
     // With the reference's MAX_BOUNCES = 100 nearly all steps run on an empty queue (Russian roulette ends paths after
@@ -547,7 +547,7 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
     }
     {
       ScopedSpan sp(c, T_SHADE);
-#define PTMI_LAUNCH_SHADE(IS, SO, CN) hipLaunchKernelGGL((k_shade<IS, SO, CN>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, tot)
+#define PTMI_LAUNCH_SHADE(IS, SO, CN) hipLaunchKernelGGL((k_shade<IS, SO, CN>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, c->d_heads.as<uint32_t>(), tot)
 #define PTMI_LAUNCH_SHADE2(IS, SO) \
   do {                             \
     if (c->counters) PTMI_LAUNCH_SHADE(IS, SO, true); \

@@ -17,6 +17,13 @@ namespace ptmi {
 
 constexpr int kBlock = 256;
 
+// k_bvh's claim counters: one per team of waves, 128 bytes apart.  Whoever fills a queue (k_generate, k_shade, k_prims)
+// zeroes them for the k_bvh launch that follows.
+constexpr uint32_t kHeadStride = 32, kMaxTeams = 64;
+DEV void reset_heads(uint32_t* __restrict__ heads) {
+  if (blockIdx.x == 0 && threadIdx.x < kMaxTeams) heads[threadIdx.x * kHeadStride] = 0u;
+}
+
 DEV void reduce_counters(const Counters& cn, unsigned long long* __restrict__ totals, bool bvh) {
   uint32_t v[5] = {cn.node_visits, cn.tri_tests, cn.sphere_tests, cn.quad_tests, cn.mat_fetches};
 #pragma unroll
@@ -32,7 +39,9 @@ DEV void reduce_counters(const Counters& cn, unsigned long long* __restrict__ to
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_generate(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, unsigned long long* __restrict__ totals) {
+__global__ __launch_bounds__(kBlock) void k_generate(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads,
+                                                     unsigned long long* __restrict__ totals) {
+  reset_heads(heads);
   const bool trace = rc.max_bounces > 0;  // MAX_BOUNCES = 0: ray_color's loop body never runs, no hitScene at all
   uint32_t total = rc.n_local * (uint32_t)rc.n_frames;
   Counters cn = {0, 0, 0, 0, 0};
@@ -90,7 +99,9 @@ DEV uint32_t bin_rank(int bin, uint32_t* s_cnt) {
 // hitScene, part 1 as a stand-alone, element-wise kernel (one slot per thread): ptmi_trace's entry into the pipeline.
 // Renders never launch it — k_generate and k_shade run prims_for_ray on the rays they create.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_prims(DevScene S, Paths P, const StepCtl* __restrict__ ctl, unsigned long long* __restrict__ totals) {
+__global__ __launch_bounds__(kBlock) void k_prims(DevScene S, Paths P, const StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads,
+                                                  unsigned long long* __restrict__ totals) {
+  reset_heads(heads);
   const uint32_t n = ctl->n_rays;
   Counters cn = {0, 0, 0, 0, 0};
   for (uint32_t slot = blockIdx.x * kBlock + threadIdx.x; slot < n; slot += gridDim.x * kBlock) {
@@ -116,7 +127,7 @@ constexpr int kRefillThreshold = 16;
 // The triangle phase of the flat traversal runs once this many lanes hold a pending leaf (or nothing else can run).
 constexpr int kLeafBatch = 16;
 constexpr uint32_t kBvhRange = 2048;  // slots a wave claims per global atomic (less when the queue is short)
-constexpr uint32_t kHeadStride = 32, kMaxTeams = 64;  // k_bvh's claim counters: one per team of waves, 128 bytes apart
+
 
 // hitScene, part 2 (hitRay.wgsl:42-110): BVH traversal by persistent, barrier-free waves.
 // One block = one wave, so LDS (the traversal stacks, stack_alloc x 512 B per wave, plus a 64-entry candidate
@@ -419,7 +430,9 @@ constexpr int kSChunk = 512;  // slots a k_shade block sorts, shades and compact
 //      global atomic (16 or so per launch), fills it across chunks — an entry that does not fit any more continues in
 //      the next region — and marks what is left at the end as holes.
 template <bool IS, bool SORT, bool COUNT>
-__global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, unsigned long long* __restrict__ totals) {
+__global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads,
+                                                                  unsigned long long* __restrict__ totals) {
+  reset_heads(heads);
   __shared__ float4 s_q0[kSChunk], s_q1[kSChunk], s_q2[kSChunk];
   __shared__ uint16_t s_sorted[SORT ? kSChunk : 1];
   __shared__ uint32_t s_cnt[NUM_BINS + 2];
