@@ -59,6 +59,7 @@ struct ptmi_ctx {
   std::vector<int32_t> h_meshes;
   bool scene_dirty = true;
 
+  DBuf d_quad_unit_n;
   DBuf d_spheres, d_sphere_info, d_quads, d_quad_mat, d_tris, d_pretri, d_meshes, d_xforms, d_mats, d_pairs, d_leaf_table;
   DevScene S{};
   int bvh_depth = 0;             // max number of inner nodes on a root-to-leaf path
@@ -334,6 +335,11 @@ int prepare_scene(ptmi_ctx* c) {
   HIP_TRY(c, up(c->d_sphere_info, sphere_info.data(), sphere_info.size() * 4));
   HIP_TRY(c, up(c->d_quads, c->h_quads.data(), c->h_quads.size() * 4));
   HIP_TRY(c, up(c->d_quad_mat, quad_mat.data(), quad_mat.size() * 4));
+  HIP_TRY(c, c->d_quad_unit_n.ensure(std::max<size_t>((size_t)n_quad * 16, 16)));
+  if (n_quad > 0) {
+    hipLaunchKernelGGL(k_quad_digest, dim3((unsigned)((n_quad + 63) / 64)), dim3(64), 0, c->stream, c->d_quads.as<float4>(), n_quad, c->d_quad_unit_n.as<float4>());
+    HIP_TRY(c, hipGetLastError());
+  }
   HIP_TRY(c, up(c->d_tris, c->h_tris.data(), c->h_tris.size() * 4));
   HIP_TRY(c, up(c->d_pretri, pretri.data(), pretri.size() * 4));
   HIP_TRY(c, up(c->d_meshes, c->h_meshes.data(), c->h_meshes.size() * 4));
@@ -348,6 +354,7 @@ int prepare_scene(ptmi_ctx* c) {
   S.sphere_info = c->d_sphere_info.as<int2>();
   S.quads = c->d_quads.as<float4>();
   S.quad_mat = c->d_quad_mat.as<int>();
+  S.quad_unit_n = c->d_quad_unit_n.as<float4>();
   S.tris = c->d_tris.as<float4>();
   S.pretri = c->d_pretri.as<float4>();
   S.meshes = c->d_meshes.as<int4>();
@@ -656,7 +663,7 @@ void ptmi_destroy(ptmi_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   drain_spans(c);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
-  for (DBuf* b : {&c->d_spheres, &c->d_sphere_info, &c->d_quads, &c->d_quad_mat, &c->d_tris, &c->d_pretri, &c->d_meshes, &c->d_xforms,
+  for (DBuf* b : {&c->d_quad_unit_n, &c->d_spheres, &c->d_sphere_info, &c->d_quads, &c->d_quad_mat, &c->d_tris, &c->d_pretri, &c->d_meshes, &c->d_xforms,
                   &c->d_mats, &c->d_pairs, &c->d_leaf_table, &c->d_fb_own, &c->d_q0[0], &c->d_q0[1], &c->d_q1[0], &c->d_q1[1], &c->d_q2[0],
                   &c->d_q2[1], &c->d_tp[0], &c->d_tp[1], &c->d_hm[0], &c->d_hm[1], &c->d_uv, &c->d_acc, &c->d_pixsum, &c->d_ctl, &c->d_totals,
                   &c->d_scratch, &c->d_spill, &c->d_heads})

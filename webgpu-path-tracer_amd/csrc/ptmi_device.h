@@ -97,6 +97,7 @@ struct DevScene {
   const int2* sphere_info;  // {material word, is_volume}
   const float4* quads;  // 5 float4 / quad
   const int* quad_mat;      // material word per quad
+  const float4* quad_unit_n;  // normalize(quad.normal), evaluated once per quad by k_quad_digest with the very same norm3()
   const float4* tris;    // 6 float4 / triangle (raw)
   const float4* pretri;  // 4 float4 / triangle
   const int4* meshes;
@@ -594,8 +595,8 @@ DEV HitGeom resolve_hit(const DevScene& S, f3 o, f3 d, float t, float u, float v
     float4 s0 = S.spheres[2 * idx];
     g.n = norm3(g.p - mk3(s0));
     g.front = true;
-  } else if (kind == K_QUAD) {  // common.wgsl:176-183
-    g.n = norm3(mk3(S.quads[5 * idx + 3]));
+  } else if (kind == K_QUAD) {  // common.wgsl:176-183: normalize(quad.normal) is a per-quad constant, read from the digest
+    g.n = mk3(S.quad_unit_n[idx]);
     g.front = dot3(d, g.n) < 0;
     if (!g.front) g.n = -g.n;
   } else {  // K_TRI, common.wgsl:224-237

@@ -632,6 +632,15 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(RenderConst rc, Paths P, 
   }
 }
 
+// Upload-time digest: the unit normal resolve_hit needs for a quad hit (common.wgsl:176), computed once per quad by the
+// same device function the shading path would call per hit — same instructions, same bits.
+__global__ void k_quad_digest(const float4* __restrict__ quads, int n, float4* __restrict__ unit_n) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n) return;
+  const f3 u = norm3(mk3(quads[5 * i + 3]));
+  unit_n[i] = make_float4(u.x, u.y, u.z, 0.0f);
+}
+
 // ---- test hooks ------------------------------------------------------------------------------------
 struct HitOut {
   int32_t hit;
