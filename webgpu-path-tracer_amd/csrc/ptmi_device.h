@@ -146,8 +146,6 @@ struct Paths {
 
 struct StepCtl {
   uint32_t n_rays;   // slots of this step's queue (holes included)
-  uint32_t pad;
-  uint32_t head_b;   // (unused: k_bvh's claim counters live in their own buffer, one per team of waves)
   uint32_t n_valid;  // slots that hold a path = hitScene invocations of this step (tallied by k_shade)
 };
 

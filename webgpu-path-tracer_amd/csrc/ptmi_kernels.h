@@ -130,12 +130,13 @@ constexpr uint32_t kBvhRange = 2048;  // slots a wave claims per global atomic (
 
 
 // hitScene, part 2 (hitRay.wgsl:42-110): BVH traversal by persistent, barrier-free waves.
-// One block = one wave, so LDS (the traversal stacks, stack_alloc x 512 B per wave, plus a 64-entry candidate
-// buffer) is the only thing that limits how many waves a CU holds.  A wave claims ranges of queue SLOTS (one global
-// atomic per <= 2048 slots), scans the HITMAT_BVH flags 64 slots at a time into its candidate buffer, and hands
-// candidates to idle lanes: each lane runs the traversal state machine on one ray, and whenever kRefillThreshold
-// lanes have finished they are refilled, so short rays never leave lanes idle behind a long one and tails exist only
-// at kernel end.
+// One block = one wave, so LDS (the first lds_entries stack entries of every lane, 512 B each, plus a candidate buffer)
+// and the 96-VGPR budget are what limit how many waves a CU holds (20).  A wave claims ranges of queue SLOTS (one global
+// atomic per <= 2048 slots, on its team's counter), scans the HITMAT_BVH flags 64 slots at a time into its candidate
+// buffer, and hands candidates to idle lanes: each lane runs the traversal state machine on one ray, and whenever
+// kRefillThreshold lanes have finished they are refilled, so short rays never leave lanes idle behind a long one and
+// tails exist only at kernel end.  (A team's waves share an XCD; dealing consecutive ranges to one team in runs of 8 or
+// 64 so that neighbouring rays share that XCD's L2 measured +-0: after the first bounce rays are incoherent.)
 // Flat traversal: one 64-byte record fetch (pair or triangle) per lane per iteration.
 //   NOABORT = the tree is shallower than STACK_SIZE (see ptmi_device.h): far children that miss outright are not pushed.
 template <bool COUNT, bool NOABORT>
