@@ -359,3 +359,68 @@ def test_sah_bvh_bit_exact(ctx, pkg, oracle):
         assert_same_bits(got, want, "sah stack %d" % stack)
         for k in ("rays", "node_visits", "tri_tests", "quad_tests", "mat_fetches"):
             assert st[k] == ost[k], (stack, k)
+
+
+def _random_scene(pkg, seed):
+    """A random scene through the Scene API: 0-4 spheres (any material type, volumes included), the Cornell quads plus 0-3
+    extra quads, 0-2 small meshes with random transforms; random materials of all four types."""
+    import math
+    from webgpu_path_tracer_amd.scenes import CornellScene
+
+    r = np.random.default_rng(1000 + seed)
+
+    def material(sc, tag):
+        ty = int(r.integers(0, 4))
+        col = [float(x) for x in r.uniform(0.1, 0.95, 3)]
+        em = [float(x) for x in (r.uniform(0, 4, 3) if r.random() < 0.15 else np.zeros(3))]
+        spec, rough = float(r.uniform(0, 0.6)), float(r.uniform(0, 1))
+        if ty == 3:  # isotropic volume: specularStrength = g of the phase function, roughness = -1/density
+            spec, rough = float(r.uniform(-0.6, 0.6)) or 0.1, -1.0 / float(r.uniform(0.5, 8))
+        return sc.add_material("m%s" % tag, ty, col, [float(x) for x in r.uniform(0.2, 1, 3)], em, spec, rough, float(r.uniform(1.1, 2.2)))
+
+    def spheres(sc):
+        for i in range(int(r.integers(0, 5))):
+            sc.add_sphere([float(x) for x in r.uniform(-0.7, 0.7, 3)], float(r.uniform(0.1, 0.45)), material(sc, "s%d" % i))
+
+    def meshes(sc):
+        for i in range(int(r.integers(0, 3))):
+            data = pkg.scenes.dragon_class_mesh(int(r.integers(60, 900)), seed=int(r.integers(1, 99)))
+            m = sc.add_mesh(data, material(sc, "t%d" % i))
+            s = float(r.uniform(0.3, 1.2))
+            axis = [float(x) for x in r.normal(0, 1, 3)]
+            m.transform.update(m.transform.scale(s, s * float(r.uniform(0.6, 1.4)), s), m.transform.rotate(float(r.uniform(0, math.pi)), axis),
+                               m.transform.translate(*[float(x) for x in r.uniform(-0.4, 0.4, 3)]))
+
+    class RandomScene(CornellScene):
+        def create_quads(self):  # the Cornell walls + light, then 0-3 free quads (any orientation, possibly degenerate-ish)
+            super().create_quads()
+            for i in range(int(r.integers(0, 4))):
+                q = [float(x) for x in r.uniform(-0.8, 0.4, 3)]
+                self.add_quad(q, [float(x) for x in r.uniform(-0.6, 0.6, 3)], [float(x) for x in r.uniform(-0.6, 0.6, 3)], material(self, "q%d" % i))
+                self.objs.append(self.quads[-1])
+
+    sc = RandomScene(spheres=spheres, meshes=meshes)
+    return sc, r
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_scenes_bit_exact(ctx, pkg, oracle, seed):
+    sc, r = _random_scene(pkg, seed)
+    b = sc.buffers(native=pkg.ptmi.NativeHost())
+    params = dict(max_bounces=int(r.integers(1, 13)), stack_size=int(r.choice([3, 8, 20, 64])), num_samples=int(r.choice([1, 1, 2])),
+                  importance_sampling=int(r.random() < 0.4), background=tuple(float(x) for x in r.uniform(0, 1, 3)))
+    ctx.upload_scene(b)
+    ctx.set_params(frames_in_flight=int(r.choice([0, 1, 3])), **params)
+    w, h = int(r.integers(20, 70)), int(r.integers(16, 50))
+    ctx.resize(w, h)
+    view = cornell_view(pkg, ["cornell", "oblique", "default"][seed % 3])
+    ctx.reset_stats()
+    ctx.set_counters(True)
+    ctx.render(view, 1 + seed, 3)
+    got = ctx.read_framebuffer()
+    st = ctx.stats()
+    ctx.set_counters(False)
+    want, ost = oracle.render(b, w, h, view, 1 + seed, 3, **params)
+    assert_same_bits(got, want, "random scene %d %r" % (seed, params))
+    for k in ("rays", "paths", "node_visits", "tri_tests", "sphere_tests", "quad_tests", "mat_fetches"):
+        assert st[k] == ost[k], (seed, k, st[k], ost[k])
