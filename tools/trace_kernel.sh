@@ -1,8 +1,9 @@
 #!/bin/bash
-# usage: tools/trace_kernel.sh <tag> <kernel substring> <bench args...> — per-launch durations (ms) of one kernel, timed pass only
+# usage: tools/trace_kernel.sh <tag> <kernel substring> [script.py] <args...>   (bench.py when no script is named) — per-launch durations (ms) of one kernel, timed pass only
 tag=$1; kern=$2; shift 2
 out=/tmp/kt_$tag; rm -rf $out; export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out -o run -- python3 bench.py "$@" > /dev/null 2>&1
+prog="bench.py"; if [[ "$1" == *.py ]]; then prog=$1; shift; fi
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out -o run -- python3 $prog "$@" > /dev/null 2>&1
 python3 - "$out" "$kern" <<'PY'
 import csv, glob, sys
 rows = []

@@ -759,10 +759,13 @@ int ptmi_render(ptmi_ctx* c, const float* view16, uint32_t first_frame, uint32_t
   if (r) return r;
   // pixels this context owns; a rank that renders 1/N of the image keeps N times more frames in flight
   const size_t npix = std::max<size_t>(1, count_local((uint32_t)c->W * (uint32_t)c->H, c->rank, c->world, c->tile));
-  // auto: as many frames per wavefront pass as a 128 M-path budget allows (64 at 1080p, 16 at 4K; ~150 B of state per
-  // path): the sparse Russian-roulette tail steps and every launch are amortised over more rays
-  uint32_t F = c->prm.frames_in_flight > 0 ? (uint32_t)c->prm.frames_in_flight : (uint32_t)std::max<size_t>(1, std::min<size_t>(1024, ((size_t)1 << 27) / npix));
-  size_t max_f = std::max<size_t>(1, (size_t)0x0fffffff / npix);  // path ids stay below 2^28
+  // auto: as many frames per wavefront pass as a 512 M-path budget allows (256 at 1080p, 64 at 4K; ~160 B of state per path
+  // = 80 of the 288 GB).  Every k_bvh launch ends with a tail as long as its longest ray (~2 ms per step on an 871 k-triangle
+  // tree, whatever the batch size: configs[2] gains 13 % from 64 -> 128 frames), and the sparse Russian-roulette steps and
+  // the launches are amortised over more rays too.  PTMI_PATH_BUDGET_LOG2 overrides (tests, smaller boards).
+  const int budget_log2 = std::max(16, std::min(31, env_int("PTMI_PATH_BUDGET_LOG2", 29)));
+  uint32_t F = c->prm.frames_in_flight > 0 ? (uint32_t)c->prm.frames_in_flight : (uint32_t)std::max<size_t>(1, std::min<size_t>(1024, ((size_t)1 << budget_log2) / npix));
+  size_t max_f = std::max<size_t>(1, ((size_t)1 << 31) / npix);  // slot indices (paths + 1/8 + holes) stay below 2^32
   F = (uint32_t)std::min<size_t>(F, max_f);
   for (uint32_t done = 0; done < n_frames;) {
     uint32_t nb = std::min(F, n_frames - done);
