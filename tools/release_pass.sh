@@ -10,7 +10,7 @@ timeout -k 10 600 python bench.py --workload c3 --steps 2 > $R/bench_c3.json 2> 
 timeout -k 10 600 python bench.py --workload c4 --steps 1 --cpu-seconds 10 > $R/bench_c4.json 2> $R/bench_c4.err || exit 1
 timeout -k 10 600 python bench.py --workload c5 --width 3840 --height 2160 --spp 128 --steps 1 --cpu-seconds 10 > $R/bench_c5.json 2> $R/bench_c5.err || exit 1
 for w in c2 c3; do
-  extra=""; [ $w = c3 ] && extra="--spp 64"
+  extra=""
   rm -rf /tmp/ks_$w; (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$w -o run -- python3 $OLDPWD/bench.py --workload $w --steps 3 --warmup 1 --cpu-seconds 0 $extra > $OLDPWD/$R/ks_$w.log 2>&1) || exit 1
   cp $(find /tmp/ks_$w -name '*kernel_stats.csv' | head -1) $R/kernel_stats_$w.csv || exit 1
   for c in FETCH_SIZE WRITE_SIZE; do
