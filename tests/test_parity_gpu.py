@@ -424,3 +424,29 @@ def test_random_scenes_bit_exact(ctx, pkg, oracle, seed):
     assert_same_bits(got, want, "random scene %d %r" % (seed, params))
     for k in ("rays", "paths", "node_visits", "tri_tests", "sphere_tests", "quad_tests", "mat_fetches"):
         assert st[k] == ost[k], (seed, k, st[k], ost[k])
+
+
+def test_device_bvh_builder_is_byte_identical_to_host(ctx, pkg):
+    """ptmi_build_bvh_device (level-synchronous, rocPRIM segmented reduce + stable segmented radix sort) against the host builder
+    — itself byte-identical to the reference's JavaScript (tests/test_host_buffers.py): random boxes with tied keys and -0, tiny
+    inputs, and the 871,414-triangle mesh of configs[2]."""
+    nh = pkg.ptmi.NativeHost()
+    rng = np.random.default_rng(17)
+    for n in (1, 2, 3, 5, 64, 1000, 70001):
+        c = rng.uniform(-1, 1, (n, 3)).astype(np.float32).astype(np.float64)
+        c[rng.integers(0, n, n // 3)] = c[0]        # tied keys: stability decides
+        c[rng.integers(0, n, max(n // 10, 1)), 1] = -0.0
+        c[rng.integers(0, n, max(n // 10, 1)), 1] = 0.0
+        e = rng.uniform(0, 0.05, (n, 3))
+        a, oa = nh.build_bvh(c - e, c + e)
+        b, ob = ctx.build_bvh(c - e, c + e)
+        assert np.array_equal(oa, ob), n
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), n
+    sc = pkg.scenes.c3_scene()
+    sc.init_mesh_data()
+    sc.create_meshes()
+    bmin = np.concatenate([m.bmin for m in sc.meshes])
+    bmax = np.concatenate([m.bmax for m in sc.meshes])
+    a, oa = nh.build_bvh(bmin, bmax)
+    b, ob = ctx.build_bvh(bmin, bmax)
+    assert np.array_equal(oa, ob) and np.array_equal(a.view(np.uint32), b.view(np.uint32))

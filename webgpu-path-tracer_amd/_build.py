@@ -1,6 +1,7 @@
 """Build recipes for the native pieces (explicit hipcc / gcc commands, outputs in-tree).
 
-libptmi.so   = csrc/ptmi.hip (HIP kernels + C ABI, gfx950) + csrc/ptmi_host.cpp (host natives)
+libptmi.so   = csrc/ptmi.hip (HIP kernels + C ABI, gfx950) + csrc/ptmi_bvh_device.hip (BVH build on the GPU, rocPRIM)
+               + csrc/ptmi_host.cpp (host natives)
 ptmi.node    = csrc/ptmi_napi.c (raw N-API binding of include/ptmi.h for the Node host), if the
                Node headers are present.
 -ffp-contract=off and no fast-math are part of the numerical contract (include/ptmi_math.h).
@@ -37,7 +38,7 @@ def _run(cmd):
 
 
 def build_lib(force=False, extra_flags=()):
-    srcs = [os.path.join(CSRC, "ptmi.hip"), os.path.join(CSRC, "ptmi_host.cpp")]
+    srcs = [os.path.join(CSRC, "ptmi.hip"), os.path.join(CSRC, "ptmi_bvh_device.hip"), os.path.join(CSRC, "ptmi_host.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in ("ptmi_device.h", "ptmi_kernels.h")] + [
         os.path.join(ROOT, "include", "ptmi.h"), os.path.join(ROOT, "include", "ptmi_math.h")]
     if not force and _newer(LIB, deps):

@@ -599,6 +599,13 @@ uint32_t u32_of_f32(float f) {  // WGSL u32(f32): truncation, clamped to the u32
 
 }  // namespace
 
+// for the other translation units of the library (ptmi_bvh_device.hip)
+int ptmi_ctx_set_device(ptmi_ctx* c) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  return PTMI_OK;
+}
+int ptmi_ctx_fail(ptmi_ctx* c, int code, const char* what) { return fail(c, code, what); }
+
 extern "C" {
 
 int ptmi_version(void) { return PTMI_API_VERSION; }

@@ -1,0 +1,284 @@
+// ptmi_bvh_device.hip — the reference's median-split BVH build (lib/BVH/bvhNode.js:21-101) and its pre-order flattening
+// with skip links (lib/BVH/bvhBuilder.js:37-54, bvhNode.js:76-93) ON THE GPU, level by level.
+//
+// Output is byte-identical to ptmi_build_bvh (the host builder) and hence to the reference's JavaScript:
+//   * a node's box is the min / max over its primitives' boxes starting from AABB() = (+1e30, -1e30): min and max are exact,
+//     so the order of the reduction does not matter (rocprim::segmented_reduce);
+//   * the split axis comes from the same three f64 subtractions and comparisons;
+//   * "stable sort of the node's primitives by bbox.min[axis]" is a stable segmented radix sort on the f64 keys (rocPRIM's
+//     radix sort is stable; -0 is normalised to +0 first, so the radix order is the order of JavaScript's `a - b`);
+//   * the pre-order id needs no counter: every leaf holds one primitive, a subtree over k primitives has 2k-1 nodes, so the
+//     children of node `id` over [start, end] split at mid are id+1 and id + 2*(mid-start+1); the skip link is handed down
+//     (left child: the right sibling; right child: the parent's link).
+// One level = one segmented reduce (6 doubles per primitive), one node kernel, one scan, one segmented sort, two element
+// kernels; ~21 levels for 871 k triangles.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/ptmi.h"
+
+namespace {
+
+struct Box6 {
+  double lo[3], hi[3];
+};
+struct BoxMerge {
+  __host__ __device__ Box6 operator()(const Box6& a, const Box6& b) const {
+    Box6 r;
+    for (int k = 0; k < 3; k++) {
+      r.lo[k] = a.lo[k] < b.lo[k] ? a.lo[k] : b.lo[k];  // Math.min / Math.max on finite values
+      r.hi[k] = a.hi[k] > b.hi[k] ? a.hi[k] : b.hi[k];
+    }
+    return r;
+  }
+};
+struct BoxOfPrim {  // order[i] -> that primitive's box
+  const double* bmin;
+  const double* bmax;
+  __host__ __device__ Box6 operator()(uint32_t p) const {
+    Box6 r;
+    for (int k = 0; k < 3; k++) r.lo[k] = bmin[3 * (size_t)p + k], r.hi[k] = bmax[3 * (size_t)p + k];
+    return r;
+  }
+};
+
+struct LevelNode {
+  uint32_t start, end;  // inclusive range in the primitive order
+  uint32_t id;          // pre-order id = row in the flattened array
+  int32_t next;         // skip link (row id), -1 = none
+};
+// segment offsets of a level's nodes, read straight from the level array (end is inclusive: [start, end] = [start, end+1))
+struct NodeOffset {  // (rocPRIM wants one iterator type for both offsets)
+  const LevelNode* p;
+  uint32_t end;
+  __host__ __device__ uint32_t operator()(uint32_t j) const { return end ? p[j].end + 1u : p[j].start; }
+};
+
+// per node of the level: write its row, decide leaf / inner, choose the axis; inner[j] = 1 if it has children
+__global__ void k_level_rows(const LevelNode* __restrict__ nodes, const Box6* __restrict__ boxes, uint32_t m, int prim_type, float* __restrict__ rows,
+                             int32_t* __restrict__ axis, uint32_t* __restrict__ inner) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const LevelNode nd = nodes[j];
+  const Box6 b = boxes[j];
+  const double e0 = b.hi[0] - b.lo[0], e1 = b.hi[1] - b.lo[1], e2 = b.hi[2] - b.lo[2];
+  int a = 0;
+  if (e1 > e0) a = 1;
+  if (e2 > (a == 0 ? e0 : e1)) a = 2;
+  float* row = rows + 12 * (size_t)nd.id;
+  row[0] = (float)b.lo[0], row[1] = (float)b.lo[1], row[2] = (float)b.lo[2];
+  row[4] = (float)b.hi[0], row[5] = (float)b.hi[1], row[6] = (float)b.hi[2];
+  row[10] = nd.next < 0 ? -1.0f : (float)nd.next;
+  const bool leaf = nd.end <= nd.start;
+  if (leaf) {  // bvhNode.js:47-53
+    row[3] = -1.0f;
+    row[7] = (float)prim_type;
+    row[8] = (float)nd.start;
+    row[9] = (float)(nd.end - nd.start + 1);
+    row[11] = 0.0f;
+  } else {
+    const uint32_t mid = nd.start + (nd.end - nd.start) / 2;
+    row[3] = (float)(nd.id + 2u * (mid - nd.start + 1u));
+    row[7] = row[8] = row[9] = -1.0f;
+    row[11] = (float)a;
+  }
+  axis[j] = a;
+  inner[j] = leaf ? 0u : 1u;
+}
+
+// children of the inner nodes, in node order (left before right), and the sort segments of this level
+__global__ void k_level_children(const LevelNode* __restrict__ nodes, const uint32_t* __restrict__ inner, const uint32_t* __restrict__ rank, uint32_t m,
+                                 LevelNode* __restrict__ next_nodes, uint32_t* __restrict__ seg_begin, uint32_t* __restrict__ seg_end) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m || !inner[j]) return;
+  const LevelNode nd = nodes[j];
+  const uint32_t r = rank[j];  // index among this level's inner nodes
+  const uint32_t mid = nd.start + (nd.end - nd.start) / 2;
+  const uint32_t lid = nd.id + 1u, rid = nd.id + 2u * (mid - nd.start + 1u);
+  next_nodes[2 * r] = LevelNode{nd.start, mid, lid, (int32_t)rid};
+  next_nodes[2 * r + 1] = LevelNode{mid + 1u, nd.end, rid, nd.next};
+  seg_begin[r] = nd.start;
+  seg_end[r] = nd.end + 1u;
+}
+
+// sort key of every primitive that sits in an inner node of this level; seg_of[i] = index of its node in the level, -1 = done
+__global__ void k_level_keys(const uint32_t* __restrict__ order, const int32_t* __restrict__ seg_of, const int32_t* __restrict__ axis, const uint32_t* __restrict__ inner,
+                             const double* __restrict__ bmin, uint32_t n, double* __restrict__ keys) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t j = seg_of[i];
+  double k = 0.0;
+  if (j >= 0 && inner[j]) k = bmin[3 * (size_t)order[i] + axis[j]] + 0.0;  // -0 -> +0: `a - b` treats them as equal
+  keys[i] = k;
+}
+
+// after the sort: which node of the NEXT level each primitive belongs to
+__global__ void k_level_descend(const LevelNode* __restrict__ nodes, const uint32_t* __restrict__ inner, const uint32_t* __restrict__ rank, uint32_t n,
+                                int32_t* __restrict__ seg_of) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t j = seg_of[i];
+  if (j < 0) return;
+  if (!inner[j]) {
+    seg_of[i] = -1;
+    return;
+  }
+  const LevelNode nd = nodes[j];
+  const uint32_t mid = nd.start + (nd.end - nd.start) / 2;
+  seg_of[i] = (int32_t)(2u * rank[j] + (i > mid ? 1u : 0u));
+}
+
+__global__ void k_iota(uint32_t* __restrict__ order, int32_t* __restrict__ seg_of, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  order[i] = i;
+  seg_of[i] = 0;
+}
+
+struct Dev {  // frees everything on scope exit
+  std::vector<void*> ptrs;
+  template <class T>
+  hipError_t alloc(T** p, size_t count) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+    if (e == hipSuccess) ptrs.push_back(q);
+    *p = (T*)q;
+    return e;
+  }
+  ~Dev() {
+    for (void* p : ptrs) (void)hipFree(p);
+  }
+};
+
+#define TRY(expr)                      \
+  do {                                 \
+    hipError_t _e = (expr);            \
+    if (_e != hipSuccess) return _e;   \
+  } while (0)
+
+hipError_t build_on_device(hipStream_t stream, uint32_t n, const double* h_bmin, const double* h_bmax, int prim_type, float* h_rows, int64_t* h_order) {
+  Dev d;
+  const uint32_t nn = 2 * n - 1;
+  double *bmin, *bmax, *keys[2];
+  uint32_t *order[2], *inner, *rank, *seg_begin, *seg_end;
+  int32_t *seg_of, *axis;
+  LevelNode* level[2];
+  Box6* boxes;
+  float* rows;
+  TRY(d.alloc(&bmin, 3 * (size_t)n));
+  TRY(d.alloc(&bmax, 3 * (size_t)n));
+  TRY(d.alloc(&keys[0], n));
+  TRY(d.alloc(&keys[1], n));
+  TRY(d.alloc(&order[0], n));
+  TRY(d.alloc(&order[1], n));
+  TRY(d.alloc(&seg_of, n));
+  TRY(d.alloc(&inner, n));
+  TRY(d.alloc(&rank, n));
+  TRY(d.alloc(&seg_begin, n));
+  TRY(d.alloc(&seg_end, n));
+  TRY(d.alloc(&axis, n));
+  TRY(d.alloc(&level[0], n));
+  TRY(d.alloc(&level[1], n));
+  TRY(d.alloc(&boxes, n));
+  TRY(d.alloc(&rows, 12 * (size_t)nn));
+  TRY(hipMemcpyAsync(bmin, h_bmin, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream));
+  TRY(hipMemcpyAsync(bmax, h_bmax, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream));
+
+  Box6 init;
+  for (int k = 0; k < 3; k++) init.lo[k] = 1e30, init.hi[k] = -1e30;  // new AABB() (AABB.js:2-5)
+  const BoxOfPrim box_of{bmin, bmax};
+
+  // temporary storage for the three rocPRIM calls at their largest size
+  size_t t_reduce = 0, t_scan = 0, t_sort = 0;
+  {
+    auto in = rocprim::make_transform_iterator(order[0], box_of);
+    TRY(rocprim::segmented_reduce(nullptr, t_reduce, in, boxes, n, seg_begin, seg_end, BoxMerge(), init, stream));
+    TRY(rocprim::exclusive_scan(nullptr, t_scan, inner, rank, 0u, n, rocprim::plus<uint32_t>(), stream));
+    TRY(rocprim::segmented_radix_sort_pairs(nullptr, t_sort, keys[0], keys[1], order[0], order[1], n, n, seg_begin, seg_end, 0, 64, stream));
+  }
+  char* temp;
+  const size_t t_bytes = std::max(t_reduce, std::max(t_scan, t_sort));
+  TRY(d.alloc(&temp, t_bytes));
+
+  const unsigned B = 256;
+  hipLaunchKernelGGL(k_iota, dim3((n + B - 1) / B), dim3(B), 0, stream, order[0], seg_of, n);
+  const LevelNode root{0u, n - 1u, 0u, -1};
+  TRY(hipMemcpyAsync(level[0], &root, sizeof root, hipMemcpyHostToDevice, stream));
+  TRY(hipStreamSynchronize(stream));  // `root` is a stack variable
+
+  uint32_t m = 1;
+  int cur = 0, ocur = 0;  // ping-pong indices of the level arrays and of the order arrays
+  while (m > 0) {
+    // node boxes: begin / end offsets of ALL nodes of the level (leaves included) come from the level array itself
+    {
+      auto idx = rocprim::counting_iterator<uint32_t>(0);
+      auto b = rocprim::make_transform_iterator(idx, NodeOffset{level[cur], 0u});
+      auto e = rocprim::make_transform_iterator(idx, NodeOffset{level[cur], 1u});
+      auto in = rocprim::make_transform_iterator(order[ocur], box_of);
+      size_t tb = t_bytes;
+      TRY(rocprim::segmented_reduce(temp, tb, in, boxes, m, b, e, BoxMerge(), init, stream));
+    }
+    hipLaunchKernelGGL(k_level_rows, dim3((m + B - 1) / B), dim3(B), 0, stream, level[cur], boxes, m, prim_type, rows, axis, inner);
+    {
+      size_t tb = t_bytes;
+      TRY(rocprim::exclusive_scan(temp, tb, inner, rank, 0u, m, rocprim::plus<uint32_t>(), stream));
+    }
+    // number of inner nodes = rank[m-1] + inner[m-1]
+    uint32_t tail[2];
+    TRY(hipMemcpyAsync(&tail[0], rank + (m - 1), 4, hipMemcpyDeviceToHost, stream));
+    TRY(hipMemcpyAsync(&tail[1], inner + (m - 1), 4, hipMemcpyDeviceToHost, stream));
+    TRY(hipStreamSynchronize(stream));
+    const uint32_t n_inner = tail[0] + tail[1];
+    if (n_inner == 0) break;
+    hipLaunchKernelGGL(k_level_children, dim3((m + B - 1) / B), dim3(B), 0, stream, level[cur], inner, rank, m, level[cur ^ 1], seg_begin, seg_end);
+    hipLaunchKernelGGL(k_level_keys, dim3((n + B - 1) / B), dim3(B), 0, stream, order[ocur], seg_of, axis, inner, bmin, n, keys[0]);
+    // primitives outside this level's inner nodes keep their place: start from a copy, the sort overwrites the segments
+    TRY(hipMemcpyAsync(order[ocur ^ 1], order[ocur], (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+    {
+      size_t tb = t_bytes;
+      TRY(rocprim::segmented_radix_sort_pairs(temp, tb, keys[0], keys[1], order[ocur], order[ocur ^ 1], n, n_inner, seg_begin, seg_end, 0, 64, stream));
+    }
+    ocur ^= 1;
+    hipLaunchKernelGGL(k_level_descend, dim3((n + B - 1) / B), dim3(B), 0, stream, level[cur], inner, rank, n, seg_of);
+    cur ^= 1;
+    m = 2 * n_inner;
+  }
+  TRY(hipGetLastError());
+  std::vector<uint32_t> ord(n);
+  TRY(hipMemcpyAsync(h_rows, rows, 12 * (size_t)nn * sizeof(float), hipMemcpyDeviceToHost, stream));
+  TRY(hipMemcpyAsync(ord.data(), order[ocur], (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+  TRY(hipStreamSynchronize(stream));
+  for (uint32_t i = 0; i < n; i++) h_order[i] = (int64_t)ord[i];
+  return hipSuccess;
+}
+
+}  // namespace
+
+// ptmi.hip supplies the context's device and error slot through these two accessors (the stream through ptmi_stream).
+int ptmi_ctx_set_device(ptmi_ctx* ctx);                        // ptmi.hip
+int ptmi_ctx_fail(ptmi_ctx* ctx, int code, const char* what);  // ptmi.hip
+
+extern "C" int ptmi_build_bvh_device(ptmi_ctx* ctx, size_t n_prims, const double* bmin, const double* bmax, int prim_type, float* nodes_out, int64_t* order_out) {
+  if (!ctx) return PTMI_ERR_INVALID_ARG;
+  if (n_prims == 0) return PTMI_OK;
+  if (!bmin || !bmax || !nodes_out || !order_out) return ptmi_ctx_fail(ctx, PTMI_ERR_INVALID_ARG, "ptmi_build_bvh_device: null argument");
+  if (n_prims > (size_t)1 << 27) return ptmi_ctx_fail(ctx, PTMI_ERR_UNSUPPORTED, "ptmi_build_bvh_device: more than 2^27 primitives");
+  int r = ptmi_ctx_set_device(ctx);
+  if (r) return r;
+  void* s = nullptr;
+  ptmi_stream(ctx, &s);
+  hipError_t e;
+  try {
+    e = build_on_device((hipStream_t)s, (uint32_t)n_prims, bmin, bmax, prim_type, nodes_out, order_out);
+  } catch (...) {
+    return ptmi_ctx_fail(ctx, PTMI_ERR_NO_MEMORY, "ptmi_build_bvh_device: host allocation failed");
+  }
+  if (e != hipSuccess) return ptmi_ctx_fail(ctx, e == hipErrorOutOfMemory ? PTMI_ERR_NO_MEMORY : PTMI_ERR_DEVICE, hipGetErrorString(e));
+  return PTMI_OK;
+}

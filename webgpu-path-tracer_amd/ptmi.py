@@ -18,7 +18,7 @@ SYMBOLS = [
     "ptmi_render_frame", "ptmi_render", "ptmi_synchronize", "ptmi_read_framebuffer", "ptmi_write_framebuffer",
     "ptmi_framebuffer_device_ptr", "ptmi_bind_framebuffer", "ptmi_stream", "ptmi_resolve_rgba8", "ptmi_set_counters",
     "ptmi_set_timing", "ptmi_get_stats", "ptmi_reset_stats", "ptmi_trace", "ptmi_math_eval", "ptmi_build_bvh",
-    "ptmi_build_bvh_sah", "ptmi_obj_parse", "ptmi_free",
+    "ptmi_build_bvh_sah", "ptmi_build_bvh_device", "ptmi_obj_parse", "ptmi_free",
 ]
 
 
@@ -100,6 +100,7 @@ def load_library(build=False):
     L.ptmi_math_eval.argtypes = [vp, i32, sz, fp, fp, fp]
     L.ptmi_build_bvh.argtypes = [sz, fp, fp, i32, fp, fp]
     L.ptmi_build_bvh_sah.argtypes = [sz, fp, fp, i32, fp, fp, ctypes.POINTER(sz)]
+    L.ptmi_build_bvh_device.argtypes = [vp, sz, fp, fp, i32, fp, fp]
     L.ptmi_obj_parse.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(vp), ctypes.POINTER(sz)]
     L.ptmi_free.argtypes = [vp]
     L.ptmi_free.restype = None
@@ -287,6 +288,16 @@ class Context:
 
     def reset_stats(self):
         self._ck(self.lib.ptmi_reset_stats(self.h))
+
+    def build_bvh(self, bmin, bmax, prim_type=2):
+        """ptmi_build_bvh_device: the median-split build on this context's GPU; same result as NativeHost.build_bvh."""
+        bmin = np.ascontiguousarray(bmin, np.float64)
+        bmax = np.ascontiguousarray(bmax, np.float64)
+        n = bmin.shape[0]
+        nodes = np.zeros((max(2 * n - 1, 0), 12), np.float32)
+        order = np.zeros(n, np.int64)
+        self._ck(self.lib.ptmi_build_bvh_device(self.h, n, _ptr(bmin), _ptr(bmax), prim_type, _ptr(nodes), _ptr(order)))
+        return nodes, order
 
     def trace(self, rays6, rng=None):
         r = np.ascontiguousarray(rays6, np.float32).reshape(-1, 6)
