@@ -58,7 +58,8 @@ typedef struct ptmi_params {
   int32_t stack_size;          /* STACK_SIZE = 20 (traversal aborts when the stack fills, Q7) */
   float background[3];         /* (0,1,1)                                                     */
   float fov_degrees;           /* 60                                                          */
-  int32_t frames_in_flight;    /* ptmi_render batches this many frames per wavefront pass; 0 = auto */
+  int32_t frames_in_flight;    /* ptmi_render batches this many frames per wavefront pass; 0 = auto: a 2^29-path budget
+                                * (256 frames at 1080p, ~80 GB of path state; PTMI_PATH_BUDGET_LOG2 overrides) */
   int32_t reserved[5];
 } ptmi_params;
 
