@@ -181,6 +181,8 @@ def main():
                 "avg_launch_ms": st["bvh_ms"] / launches,
                 "launches": launches,
                 "hit_scene_algorithmic_gbs": hit_scene,
+                "note": "k_bvh is bound by VALU issue and fetch latency (rocprofv3 PMC: ~66 % VALU busy at ~54 % active lanes on deep trees), not by HBM: "
+                        "algorithmic bytes are reference-layout bytes, most of them served by L2 / Infinity Cache, so frac can exceed 1 (DESIGN.md section 5)",
                 "work_per_ray": {k: cst[k] / max(cst["rays"], 1) for k in ("node_visits", "bvh_node_visits", "tri_tests", "quad_tests", "sphere_tests", "mat_fetches")},
                 "kernel_ms_one_step_counted_pass": {"prims": cst["prims_ms"], "bvh": cst["bvh_ms"], "shade": cst["shade_ms"], "other": cst["other_ms"], "render": cst["render_ms"]},
             },
