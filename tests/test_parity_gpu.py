@@ -450,3 +450,46 @@ def test_device_bvh_builder_is_byte_identical_to_host(ctx, pkg):
     a, oa = nh.build_bvh(bmin, bmax)
     b, ob = ctx.build_bvh(bmin, bmax)
     assert np.array_equal(oa, ob) and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_render_frame_render_ahead_is_invisible(ctx, pkg, oracle, monkeypatch):
+    """ptmi_render_frame renders frames ahead once the camera rests (batches of 8, 16, ...): the framebuffer after EVERY call
+    must be what frame-by-frame tracing gives — checked against the oracle at several points, across a camera move with
+    resetBuffer, a gap in the frame numbers, a parameter change and a clear in between."""
+    b = _setup(ctx, pkg, "c2m", 80, 48, max_bounces=5)
+    v1, v2 = cornell_view(pkg), cornell_view(pkg, "oblique")
+    u = lambda f, reset, v: np.concatenate([[80, 48, f, reset], v]).astype(np.float32)
+
+    def expect(frames, view, reset_first=0, fb=None, **params):
+        out = fb
+        for i, f in enumerate(frames):
+            out, _ = oracle.render(b, 80, 48, view, f, 1, reset_first=(reset_first if i == 0 else 0), framebuffer=out, **params)
+        return out
+
+    for f in range(1, 31):  # static camera: batches are rendered ahead from the 4th frame on
+        ctx.render_frame(u(f, 0, v1))
+        if f in (1, 3, 4, 5, 12, 13, 30):
+            assert_same_bits(ctx.read_framebuffer(), expect(range(1, f + 1), v1, max_bounces=5), "static frame %d" % f)
+    # camera moves: reset, new view, frame numbers restart (renderer.js:174-181)
+    ctx.render_frame(u(1, 1, v2))
+    want = expect([1], v2, reset_first=1, fb=ctx.read_framebuffer() * 0 + 7, max_bounces=5)
+    assert_same_bits(ctx.read_framebuffer(), want, "after the move")
+    for f in range(2, 12):
+        ctx.render_frame(u(f, 0, v2))
+    want = expect(range(2, 12), v2, fb=want, max_bounces=5)
+    assert_same_bits(ctx.read_framebuffer(), want, "static again")
+    ctx.render_frame(u(20, 0, v2))  # a gap in the frame numbers: what was rendered ahead (12, 13, ...) must not be used
+    want = expect([20], v2, fb=want, max_bounces=5)
+    assert_same_bits(ctx.read_framebuffer(), want, "after the gap")
+    for f in range(21, 26):
+        ctx.render_frame(u(f, 0, v2))
+    want = expect(range(21, 26), v2, fb=want, max_bounces=5)
+    ctx.set_params(max_bounces=3)  # frames rendered ahead with 5 bounces are void now
+    for f in range(26, 30):
+        ctx.render_frame(u(f, 0, v2))
+    want = expect(range(26, 30), v2, fb=want, max_bounces=3)
+    assert_same_bits(ctx.read_framebuffer(), want, "after set_params")
+    ctx.clear()  # the display pass's clear-on-reset does not touch what was rendered ahead
+    for f in range(30, 40):
+        ctx.render_frame(u(f, 0, v2))
+    assert_same_bits(ctx.read_framebuffer(), expect(range(30, 40), v2, max_bounces=3), "after clear")

@@ -79,6 +79,22 @@ struct ptmi_ctx {
   DBuf d_uv, d_acc, d_pixsum, d_ctl, d_totals, d_scratch, d_spill, d_heads;
   int ctl_cap = 0;
 
+  // Render-ahead of ptmi_render_frame (see there): per-frame colours of frames [frame0, frame0 + count) sit in d_acc,
+  // the first `next` of them are already in the framebuffer.
+  struct Ahead {
+    bool valid = false;
+    float view[16];
+    uint32_t frame0 = 0;
+    int count = 0, next = 0;
+    RenderConst rc;
+    uint32_t grid = 1;
+  } ahead;
+  bool have_last_frame = false;
+  uint32_t last_frame = 0;
+  float last_view[16];
+  int static_streak = 0;  // consecutive ptmi_render_frame calls with the same view, frame numbers +1, no reset
+  int ahead_batch = 8;
+
   bool counters = false;
   int timing = 0;  // 0 off, 1 every kernel, 2 only k_bvh (the dominant kernel) — see ptmi_set_timing
   ptmi_stats stats{};
@@ -483,8 +499,10 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
   return PTMI_OK;
 }
 
-int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames, int reset_first) {
+// `fold` = how many of the batch's leading frames are added to the framebuffer now (-1 = all of them)
+int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames, int reset_first, int fold = -1) {
   const ptmi_params& p = c->prm;
+  c->ahead.valid = false;  // the path buffers are about to be overwritten
   RenderConst rc{};
   rc.W = (float)c->W;
   rc.H = (float)c->H;
@@ -575,10 +593,13 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   }
   {
     ScopedSpan s(c, T_OTHER);
-    hipLaunchKernelGGL(k_accumulate, dim3(ew_grid), dim3(kBlock), 0, c->stream, rc, paths_of(c, 0, false), c->fb, ctl, n_steps, tot);
+    hipLaunchKernelGGL(k_accumulate, dim3(ew_grid), dim3(kBlock), 0, c->stream, rc, paths_of(c, 0, false), c->fb, ctl, n_steps, tot, 0,
+                       fold < 0 ? n_frames : std::min(fold, n_frames));
   }
   HIP_TRY(c, hipGetLastError());
   c->stats.frames += (uint64_t)n_frames;
+  c->ahead.rc = rc;
+  c->ahead.grid = ew_grid;
   return PTMI_OK;
 }
 
@@ -687,6 +708,7 @@ int ptmi_set_params(ptmi_ctx* c, const ptmi_params* p) {
     return fail(c, PTMI_ERR_UNSUPPORTED, "ptmi_set_params: num_samples * max_bounces > 65536");
   if (!(p->fov_degrees > 0.0f && p->fov_degrees < 180.0f)) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_set_params: fov_degrees must be in (0,180)");
   c->prm = *p;
+  c->ahead.valid = false;
   return PTMI_OK;
 }
 
@@ -714,6 +736,7 @@ int ptmi_upload(ptmi_ctx* c, int which, const void* data, size_t bytes) {
     case PTMI_BUF_BVH: c->h_bvh.assign(f, f + bytes / 4); break;
   }
   c->scene_dirty = true;
+  c->ahead.valid = false;
   return PTMI_OK;
 }
 
@@ -723,6 +746,7 @@ int ptmi_resize(ptmi_ctx* c, int width, int height) {
     return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_resize: need 0 < W*H <= 2^28");
   HIP_TRY(c, hipSetDevice(c->device));
   size_t bytes = (size_t)width * height * 16;
+  c->ahead.valid = false;
   HIP_TRY(c, c->d_fb_own.ensure(bytes));
   c->fb = c->d_fb_own.as<float4>();
   c->fb_bytes = bytes;
@@ -743,6 +767,7 @@ int ptmi_set_shard(ptmi_ctx* c, int rank, int world, int tile_pixels) {
   if (!c) return PTMI_ERR_INVALID_ARG;
   if (world < 1 || rank < 0 || rank >= world || tile_pixels < 1) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_set_shard: need 0 <= rank < world, tile_pixels >= 1");
   c->rank = rank, c->world = world, c->tile = tile_pixels;
+  c->ahead.valid = false;
   return PTMI_OK;
 }
 
@@ -754,7 +779,46 @@ int ptmi_render_frame(ptmi_ctx* c, const float* u) {
   r = check_renderable(c);
   if (r) return r;
   if (u[0] != (float)c->W || u[1] != (float)c->H) return fail(c, PTMI_ERR_STATE, "ptmi_render_frame: uniforms screenDims differ from ptmi_resize");
-  return render_batch(c, u + 4, u32_of_f32(u[2]), 1, u[3] == 0.0f ? 0 : 1);
+  const uint32_t k = u32_of_f32(u[2]);
+  const int reset = u[3] == 0.0f ? 0 : 1;
+  const float* view = u + 4;
+  // Render-ahead.  The reference's loop asks for one frame at a time (renderer.js:173-188) and a lone frame cannot fill the
+  // machine: every k_bvh launch lasts as long as its longest ray (7.6 ms per 1080p frame on an 871 k-triangle scene against
+  // 0.8 ms per frame in a batch).  Once the camera has been at rest for a few frames, the frames that will be asked for
+  // next are traced in the same pass; their colours wait in d_acc and each later call only adds its frame to the
+  // framebuffer — bit for bit what tracing it then would have produced.  A different view, a reset, a gap in the frame
+  // numbers or any call that touches the path buffers drops what was rendered ahead.  PTMI_RENDER_AHEAD=0 turns it off.
+  ptmi_ctx::Ahead& A = c->ahead;
+  const bool follows = c->have_last_frame && !reset && k == c->last_frame + 1u && memcmp(view, c->last_view, 64) == 0;
+  c->static_streak = follows ? c->static_streak + 1 : 0;
+  c->have_last_frame = true;
+  c->last_frame = k;
+  memcpy(c->last_view, view, 64);
+  if (A.valid && follows && A.next < A.count && k == A.frame0 + (uint32_t)A.next && memcmp(view, A.view, 64) == 0) {
+    hipLaunchKernelGGL(k_accumulate, dim3(A.grid), dim3(kBlock), 0, c->stream, A.rc, paths_of(c, 0, false), c->fb, c->d_ctl.as<StepCtl>(), 0,
+                       c->d_totals.as<unsigned long long>(), A.next, A.next + 1);
+    HIP_TRY(c, hipGetLastError());
+    A.next++;
+    return PTMI_OK;
+  }
+  int batch = 1;
+  if (c->static_streak >= 2 && !c->counters && c->timing == 0 && env_int("PTMI_RENDER_AHEAD", 1) != 0) {
+    const size_t npix = std::max<size_t>(1, count_local((uint32_t)c->W * (uint32_t)c->H, c->rank, c->world, c->tile));
+    batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)c->ahead_batch, ((size_t)1 << 29) / npix));
+    c->ahead_batch = std::min(64, c->ahead_batch * 2);  // 8, 16, 32, 64 frames while the camera stays put
+  } else {
+    c->ahead_batch = 8;
+  }
+  r = render_batch(c, view, k, batch, reset, 1);
+  if (r) return r;
+  if (batch > 1) {
+    A.valid = true;
+    memcpy(A.view, view, 64);
+    A.frame0 = k;
+    A.count = batch;
+    A.next = 1;
+  }
+  return PTMI_OK;
 }
 
 int ptmi_render(ptmi_ctx* c, const float* view16, uint32_t first_frame, uint32_t n_frames) {
@@ -827,6 +891,7 @@ int ptmi_bind_framebuffer(ptmi_ctx* c, void* dev_ptr, size_t bytes) {
     return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_bind_framebuffer: need a 16-byte aligned device pointer of >= W*H*16 bytes");
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->ahead.valid = false;
   c->fb = (float4*)dev_ptr;
   c->fb_bytes = (size_t)c->W * c->H * 16;
   return PTMI_OK;
@@ -899,6 +964,7 @@ int ptmi_trace(ptmi_ctx* c, size_t n, const float* rays6, uint32_t* rng_inout, p
   HIP_TRY(c, hipSetDevice(c->device));
   int r = prepare_scene(c);
   if (r) return r;
+  c->ahead.valid = false;
   r = ensure_paths(c, n, 4, false);
   if (r) return r;
   Paths P = paths_of(c, 0, false);

@@ -607,14 +607,15 @@ __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, Re
   if (COUNT) reduce_counters(cn, totals, false);
 }
 
-// main.wgsl:22-27 for all frame slots of the batch, in frame order; also tallies rays/paths.
+// main.wgsl:22-27 for the frame slots [f_begin, f_end) of the batch, in frame order; the call that folds slot 0 also
+// tallies the batch's rays/paths.  (ptmi_render_frame's render-ahead folds one slot per call.)
 __global__ __launch_bounds__(kBlock) void k_accumulate(RenderConst rc, Paths P, float4* __restrict__ fb, const StepCtl* __restrict__ ctl, int n_steps,
-                                                       unsigned long long* __restrict__ totals) {
+                                                       unsigned long long* __restrict__ totals, int f_begin, int f_end) {
   for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < rc.n_local; j += gridDim.x * kBlock) {
     uint32_t pix = local_to_pixel(rc, j);
     float4 cur = fb[pix];
     f3 c = mk3(cur);
-    for (int f = 0; f < rc.n_frames; f++) {
+    for (int f = f_begin; f < f_end; f++) {
       float4 a = P.acc[(size_t)f * rc.n_local + j];
       f3 col = mk3(a);
       if (f == 0 && rc.reset_first) {
@@ -625,7 +626,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(RenderConst rc, Paths P, 
     }
     fb[pix] = make_float4(c.x, c.y, c.z, 1.0f);
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (f_begin == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
     unsigned long long rays = 0;
     for (int s = 0; s < n_steps; s++) rays += ctl[s].n_valid;
     totals[0] += rays;
