@@ -86,11 +86,17 @@ def test_wgsl_header_constants_become_params():
 def test_node_host_renders_bit_exact(tmp_path, pkg, oracle):
     """Renderer (JS) -> WebGPU shim -> ptmi.node -> libptmi.so -> HIP, compared with the oracle."""
     raw = tmp_path / "fb.f32"
-    out = _run([node, "app.mjs", "--golden", os.path.join(ROOT, "tests", "golden", "c2m"), "--width", "160", "--height", "96", "--frames", "3", "--bounces", "7",
-                "--camera", "oblique", "--raw", str(raw)], cwd=JS)
+    b = pkg.scenes.golden_buffers("c2m")
+    args = [node, "app.mjs", "--golden", os.path.join(ROOT, "tests", "golden", "c2m"), "--width", "160", "--height", "96", "--bounces", "7", "--camera", "oblique", "--raw", str(raw)]
+    # exact work counters: without render-ahead (ptmi_render_frame would trace frames 3..10 when asked for the third)
+    out = _run(args + ["--frames", "3"], cwd=JS, env=dict(os.environ, PTMI_RENDER_AHEAD="0"))
     st = json.loads(out)["stats"]
     got = np.fromfile(raw, np.float32).reshape(96, 160, 4)
-    b = pkg.scenes.golden_buffers("c2m")
     want, ost = oracle.render(b, 160, 96, cornell_view(pkg, "oblique"), 1, 3, max_bounces=7)
     assert_same_bits(got, want, "node host")
     assert st["rays"] == ost["rays"] and st["frames"] == 3
+    # the default: frames are rendered ahead while the camera rests; the image after 13 calls is the 13-frame image
+    _run(args + ["--frames", "13"], cwd=JS)
+    got = np.fromfile(raw, np.float32).reshape(96, 160, 4)
+    want, _ = oracle.render(b, 160, 96, cornell_view(pkg, "oblique"), 1, 13, max_bounces=7)
+    assert_same_bits(got, want, "node host, render-ahead")
