@@ -44,6 +44,7 @@ FN(ptmi_get_stats)
 FN(ptmi_reset_stats)
 FN(ptmi_build_bvh)
 FN(ptmi_build_bvh_sah)
+FN(ptmi_build_bvh_device)
 FN(ptmi_obj_parse)
 FN(ptmi_free)
 
@@ -78,7 +79,7 @@ static int load_lib(char* err, size_t errlen) {
   LOAD(ptmi_version) LOAD(ptmi_last_error) LOAD(ptmi_create) LOAD(ptmi_destroy) LOAD(ptmi_default_params) LOAD(ptmi_set_params)
   LOAD(ptmi_get_params) LOAD(ptmi_upload) LOAD(ptmi_resize) LOAD(ptmi_clear_framebuffer) LOAD(ptmi_set_shard) LOAD(ptmi_render_frame)
   LOAD(ptmi_render) LOAD(ptmi_synchronize) LOAD(ptmi_read_framebuffer) LOAD(ptmi_write_framebuffer) LOAD(ptmi_resolve_rgba8)
-  LOAD(ptmi_set_counters) LOAD(ptmi_set_timing) LOAD(ptmi_get_stats) LOAD(ptmi_reset_stats) LOAD(ptmi_build_bvh) LOAD(ptmi_build_bvh_sah)
+  LOAD(ptmi_set_counters) LOAD(ptmi_set_timing) LOAD(ptmi_get_stats) LOAD(ptmi_reset_stats) LOAD(ptmi_build_bvh) LOAD(ptmi_build_bvh_sah) LOAD(ptmi_build_bvh_device)
   LOAD(ptmi_obj_parse) LOAD(ptmi_free)
   return 0;
 }
@@ -460,9 +461,15 @@ static napi_value js_reset_stats(napi_env env, napi_callback_info info) {
 }
 
 /* buildBVH(bmin: Float64Array(3n), bmax: Float64Array(3n), primType) -> { nodes: Float32Array, order: Int32Array } */
-static napi_value build_bvh_common(napi_env env, napi_callback_info info, int sah) {
-  napi_value a[3];
-  if (get_args(env, info, 3, a)) return NULL;
+static napi_value build_bvh_common(napi_env env, napi_callback_info info, int sah) { /* sah: 0 median (host), 1 SAH (host), 2 median on the GPU of ctx */
+  napi_value all[4];
+  if (get_args(env, info, sah == 2 ? 4 : 3, all)) return NULL;
+  ptmi_ctx* c = NULL;
+  if (sah == 2) {
+    c = ctx_of(env, all[0]);
+    if (!c) return NULL;
+  }
+  napi_value* a = all + (sah == 2 ? 1 : 0);
   void *bmin, *bmax;
   size_t l0, l1;
   if (typed(env, a[0], napi_float64_array, "buildBVH(bmin)", &bmin, &l0) || typed(env, a[1], napi_float64_array, "buildBVH(bmax)", &bmax, &l1)) return NULL;
@@ -483,11 +490,12 @@ static napi_value build_bvh_common(napi_env env, napi_callback_info info, int sa
     return NULL;
   }
   size_t rows = nn;
-  int st = sah ? p_ptmi_build_bvh_sah(n, (const double*)bmin, (const double*)bmax, pt, (float*)pn, tmp, &rows)
-               : p_ptmi_build_bvh(n, (const double*)bmin, (const double*)bmax, pt, (float*)pn, tmp);
+  int st = sah == 1   ? p_ptmi_build_bvh_sah(n, (const double*)bmin, (const double*)bmax, pt, (float*)pn, tmp, &rows)
+           : sah == 2 ? p_ptmi_build_bvh_device(c, n, (const double*)bmin, (const double*)bmax, pt, (float*)pn, tmp)
+                      : p_ptmi_build_bvh(n, (const double*)bmin, (const double*)bmax, pt, (float*)pn, tmp);
   if (st) {
     free(tmp);
-    return throw_status(env, NULL, st, sah ? "ptmi_build_bvh_sah" : "ptmi_build_bvh");
+    return throw_status(env, c, st, sah == 1 ? "ptmi_build_bvh_sah" : sah == 2 ? "ptmi_build_bvh_device" : "ptmi_build_bvh");
   }
   for (size_t i = 0; i < n; i++) ((int32_t*)po)[i] = (int32_t)tmp[i];
   free(tmp);
@@ -502,6 +510,8 @@ static napi_value build_bvh_common(napi_env env, napi_callback_info info, int sa
 static napi_value js_build_bvh(napi_env env, napi_callback_info info) { return build_bvh_common(env, info, 0); }
 /* buildBVHSAH(...): same arguments; the reference's binned-SAH builder (lib/BVH/bvhNode.js:108-283), opt-in */
 static napi_value js_build_bvh_sah(napi_env env, napi_callback_info info) { return build_bvh_common(env, info, 1); }
+/* buildBVHDevice(ctx, bmin, bmax, primType): the median-split build on the context's GPU, same result as buildBVH */
+static napi_value js_build_bvh_device(napi_env env, napi_callback_info info) { return build_bvh_common(env, info, 2); }
 
 /* parseObj(text: string | Uint8Array) -> { vertices: Float32Array, normals: Float32Array }  (objReader.js grammar) */
 static napi_value js_parse_obj(napi_env env, napi_callback_info info) {
@@ -570,7 +580,7 @@ static napi_value init(napi_env env, napi_value exports) {
       {"upload", js_upload}, {"resize", js_resize}, {"clear", js_clear}, {"setShard", js_set_shard}, {"renderFrame", js_render_frame},
       {"render", js_render}, {"synchronize", js_synchronize}, {"readFramebuffer", js_read_fb}, {"writeFramebuffer", js_write_fb},
       {"resolveRGBA8", js_resolve}, {"setCounters", js_set_counters}, {"setTiming", js_set_timing}, {"stats", js_stats},
-      {"resetStats", js_reset_stats}, {"buildBVH", js_build_bvh}, {"buildBVHSAH", js_build_bvh_sah}, {"parseObj", js_parse_obj},
+      {"resetStats", js_reset_stats}, {"buildBVH", js_build_bvh}, {"buildBVHSAH", js_build_bvh_sah}, {"buildBVHDevice", js_build_bvh_device}, {"parseObj", js_parse_obj},
   };
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
     napi_value f;
