@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--bvh", default="median", choices=["median", "sah"],
                     help="median = the reference's live builder (default, what the metric is quoted on); sah = the reference's "
                          "other, never-called builder (lib/BVH/bvhNode.js:108-283) as an opt-in (not for c2's golden buffers)")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="N>1 on ONE GPU for rehearsal: ranks share cuda:0, the framebuffer reduce goes through gloo on host copies "
+                         "(RCCL wants one device per rank); numbers from this mode are not bench results")
     ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the cpu_baseline (the 1-GPU box's CPU share)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -56,7 +59,9 @@ def main():
     pkg = entry._load_pkg()
     from webgpu_path_tracer_amd import dist as pdist
 
-    rank, world, local = pdist.init_process_group()
+    rank, world, local = pdist.init_process_group("gloo" if args.rehearse_gloo else None)
+    if args.rehearse_gloo:
+        local = 0
     if world != max(args.gpus, 1):
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     torch.cuda.set_device(local)
@@ -98,7 +103,12 @@ def main():
         ctx.clear()
         ctx.render(view, 1, spp)
         ctx.synchronize()
-        if world > 1:
+        if world > 1 and args.rehearse_gloo:
+            host = fb_t.cpu()
+            pdist.reduce_framebuffer(host, 0)
+            fb_t.copy_(host)
+            torch.cuda.synchronize()
+        elif world > 1:
             pdist.reduce_framebuffer(fb_t, 0)
             torch.cuda.synchronize()  # the reduce runs on torch's stream; the next clear runs on the context's
 
