@@ -38,7 +38,30 @@ DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
 DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 DEV f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
-DEV f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+// (a.x / s, a.y / s, a.z / s): three IEEE-754 f32 divisions by one divisor, through ONE f64 reciprocal.
+// The expansion of a correctly rounded f32 division is 11 instructions; this is 6 for the reciprocal + 4 per component.
+// Why the bits are the same: r = 1/s in f64, refined by two Newton steps from v_rcp_f64, is within 1 ulp64; x * r, rounded
+// to f64, is then within 2^-51 of x/s (relative).  A quotient of two f32 numbers that is not representable lies at least
+// 2^-49 (relative) away from every f32 rounding boundary — write a = A*2^i, b = B*2^j, boundary (2M+1)*2^(k-1) with 24-bit
+// A, B, M: the difference is a non-zero integer multiple of a power of two over B — so the f64 value rounds to f32 exactly
+// as the infinitely precise quotient does (and overflow to inf, signed zeros, inf and NaN operands come out of the
+// multiplication as they do out of the division).  The two exceptions are redone with the real division: a divisor that is
+// 0, inf or NaN (the Newton steps turn those into NaN), and a SUBNORMAL quotient, where exact ties exist (the grid is
+// coarser than the quotient's precision) and a tie must not be broken by the 2^-51.
+__device__ __attribute__((noinline)) f3 div3_ieee(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }  // the rare path, kept out of line
+DEV f3 operator/(f3 a, float s) {
+  const double ds = (double)s;
+  double r = __builtin_amdgcn_rcp(ds);
+  double e = __builtin_fma(-ds, r, 1.0);
+  r = __builtin_fma(e, r, r);
+  e = __builtin_fma(-ds, r, 1.0);
+  r = __builtin_fma(e, r, r);
+  f3 q = mk3((float)((double)a.x * r), (float)((double)a.y * r), (float)((double)a.z * r));
+  constexpr int kDenorm = 0x090, kZeroInfNan = 0x267;  // v_cmp_class masks: +-denormal; +-0, +-inf, sNaN, qNaN
+  if (__builtin_amdgcn_class(s, kZeroInfNan) | __builtin_amdgcn_class(q.x, kDenorm) | __builtin_amdgcn_class(q.y, kDenorm) | __builtin_amdgcn_class(q.z, kDenorm))
+    q = div3_ieee(a, s);
+  return q;
+}
 DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 DEV f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
@@ -198,7 +221,7 @@ DEV void camera_ray(const RenderConst& rc, uint32_t pix, int k, uint32_t& rng, f
   float dz = ((m[2] * a + m[6] * b) + m[10] * nf) + m[14] * 0.0f;
   float dw = ((m[3] * a + m[7] * b) + m[11] * nf) + m[15] * 0.0f;
   float len = ptm_sqrt(((dx * dx + dy * dy) + dz * dz) + dw * dw);  // normalize() of the vec4, then .xyz
-  d = mk3(dx / len, dy / len, dz / len);
+  d = mk3(dx, dy, dz) / len;
   // cam_origin = (view * (0,0,0,1)).xyz  (main.wgsl:8)
   o = mk3(((m[0] * 0.0f + m[4] * 0.0f) + m[8] * 0.0f) + m[12] * 1.0f, ((m[1] * 0.0f + m[5] * 0.0f) + m[9] * 0.0f) + m[13] * 1.0f,
           ((m[2] * 0.0f + m[6] * 0.0f) + m[10] * 0.0f) + m[14] * 1.0f);
