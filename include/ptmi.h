@@ -163,7 +163,8 @@ int ptmi_reset_stats(ptmi_ctx* ctx);
  * dir), each with its own RNG state (consumed by hit_volume only; may be NULL). */
 int ptmi_trace(ptmi_ctx* ctx, size_t n, const float* rays6, uint32_t* rng_inout, ptmi_hit* out);
 /* Test hook: evaluates include/ptmi_math.h functions ON THE DEVICE.
- * fn: 0 sin 1 cos 2 acos 3 log 4 log2 5 exp2 6 pow(x,y) 7 sqrt 8 min(x,y) 9 max(x,y) 10 x/y */
+ * fn: 0 sin 1 cos 2 acos 3 log 4 log2 5 exp2 6 pow(x,y) 7 sqrt 8 min(x,y) 9 max(x,y) 10 x/y
+ *     11..13 = components of (x, x*2^-20, x*2^20) / y through the device's vector division */
 int ptmi_math_eval(ptmi_ctx* ctx, int fn, size_t n, const float* x, const float* y, float* out);
 
 /* ---- host-side natives (no GPU needed) -------------------------------------------------------- */

@@ -76,3 +76,23 @@ def test_device_math_is_bit_identical_to_host(ctx, oracle):
     B = np.concatenate([B, rng.normal(0, 10, 100000).astype(np.float32)])
     for name in ("min", "max", "div"):
         assert_same_bits(ctx.math_eval(FN[name], A, B), oracle.math_eval(FN[name], A, B), name)
+
+
+@pytest.mark.gpu
+def test_device_vector_division_is_ieee_division(ctx, oracle):
+    """operator/(f3, float) on the device goes through ONE f64 reciprocal (ptmi_device.h): it must return the bits of three IEEE
+    f32 divisions for every operand, including the cases its proof excludes and sends to the real division — divisors 0 / inf /
+    NaN and subnormal quotients with exact ties (k * 2^-149 / 6 ...) — and overflow, signed zeros, huge and tiny operands."""
+    rng = np.random.default_rng(3)
+    sp = np.array([0, -0.0, 1, -1, 3, 6, 10, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 3e-45, 4.2e-45, 1.2e-38, 1.1754944e-38, 3.4e38, -3.4e38,
+                   1e-30, 1e30, 2**-126, 2**-127, 2**-149, 3 * 2**-149, 5 * 2**-149, 2**127, 0.1, 1 / 3, 1 - 2**-24, 1 + 2**-23], np.float32)
+    A, B = [m.reshape(-1) for m in np.meshgrid(sp, sp)]
+    n = 400000
+    logu = lambda lo, hi, k: (np.exp2(rng.uniform(lo, hi, k)) * rng.choice([-1.0, 1.0], k)).astype(np.float32)
+    parts_a = [A, rng.normal(0, 1, n).astype(np.float32), logu(-149, 128, n), logu(-149, -100, n), (rng.integers(1, 4000, n) * 2.0**-149).astype(np.float32)]
+    parts_b = [B, rng.normal(0, 1, n).astype(np.float32), logu(-149, 128, n), logu(-20, 60, n), rng.integers(1, 64, n).astype(np.float32)]
+    a, b = np.concatenate(parts_a), np.concatenate(parts_b)
+    with np.errstate(all="ignore"):
+        for fn, scale in ((11, np.float32(1)), (12, np.float32(2.0**-20)), (13, np.float32(2.0**20))):
+            want = oracle.math_eval(FN["div"], (a * scale).astype(np.float32), b)
+            assert_same_bits(ctx.math_eval(fn, a, b), want, "vector division, component %d" % (fn - 11))

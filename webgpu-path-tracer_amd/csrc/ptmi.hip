@@ -997,7 +997,7 @@ int ptmi_trace(ptmi_ctx* c, size_t n, const float* rays6, uint32_t* rng_inout, p
 
 int ptmi_math_eval(ptmi_ctx* c, int fn, size_t n, const float* x, const float* y, float* out) {
   if (!c || !x || !out) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_math_eval: null argument");
-  if (fn < 0 || fn > 10) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_math_eval: unknown function id");
+  if (fn < 0 || fn > 13) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_math_eval: unknown function id");
   if (n == 0) return PTMI_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   DBuf dx, dy, dout;

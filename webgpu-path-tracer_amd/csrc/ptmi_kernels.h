@@ -698,6 +698,10 @@ __global__ void k_math_eval(int fn, size_t n, const float* __restrict__ x, const
     case 8: r = ptm_min(a, b); break;
     case 9: r = ptm_max(a, b); break;
     case 10: r = a / b; break;
+    // 11..13: the components of (a, a * 2^-20, a * 2^20) / b through operator/(f3, float) — the f64-reciprocal vector division
+    case 11: r = (mk3(a, a * 9.5367431640625e-07f, a * 1048576.0f) / b).x; break;
+    case 12: r = (mk3(a, a * 9.5367431640625e-07f, a * 1048576.0f) / b).y; break;
+    case 13: r = (mk3(a, a * 9.5367431640625e-07f, a * 1048576.0f) / b).z; break;
   }
   out[i] = r;
 }
