@@ -149,7 +149,8 @@ def main():
     launches = max(st["intersect_launches"], 1)
     bvh_s = st["bvh_ms"] / 1e3
     achieved = bvh_bytes / bvh_s / 1e9 if bvh_s > 0 else 0.0
-    hit_scene = (bytes_total / args.steps) / (cst["intersect_ms"] / 1e3) / 1e9 if cst["intersect_ms"] > 0 else 0.0
+    # all of hitScene's algorithmic bytes (part 1 runs inside k_generate / k_shade) over the whole render of the counted pass
+    hit_scene = (bytes_total / args.steps) / (cst["render_ms"] / 1e3) / 1e9 if cst["render_ms"] > 0 else 0.0
     traffic = None
     prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(prof):
@@ -190,7 +191,7 @@ def main():
                 "algorithmic_bytes_per_launch": bvh_bytes / launches,
                 "avg_launch_ms": st["bvh_ms"] / launches,
                 "launches": launches,
-                "hit_scene_algorithmic_gbs": hit_scene,
+                "hit_scene_algorithmic_gbs_whole_render": hit_scene,
                 "note": "k_bvh is bound by VALU issue and fetch latency (rocprofv3 PMC: ~66 % VALU busy at ~54 % active lanes on deep trees), not by HBM: "
                         "algorithmic bytes are reference-layout bytes, most of them served by L2 / Infinity Cache, so frac can exceed 1 (DESIGN.md section 5)",
                 "work_per_ray": {k: cst[k] / max(cst["rays"], 1) for k in ("node_visits", "bvh_node_visits", "tri_tests", "quad_tests", "sphere_tests", "mat_fetches")},
