@@ -40,8 +40,8 @@ DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 DEV f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
 // (a.x / s, a.y / s, a.z / s): three IEEE-754 f32 divisions by one divisor, through ONE f64 reciprocal.
 // The expansion of a correctly rounded f32 division is 11 instructions; this is 6 for the reciprocal + 4 per component.
-// Why the bits are the same: r = 1/s in f64, refined by two Newton steps from v_rcp_f64 (measured on MI355X: 2^-24.4 relative
-// error as it comes, 2^-48.7 after one step — not enough — and rounding-limited after two), is within 1 ulp64; x * r, rounded
+// Why the bits are the same: r = 1/s in f64, v_rcp_f64 refined by one third-order step (measured on MI355X: 2^-24.4 relative
+// error as it comes, 2^-48.7 after one Newton step — not enough — so the step is r(1 + e + e^2)), is within 1 ulp64; x * r, rounded
 // to f64, is then within 2^-51 of x/s (relative).  A quotient of two f32 numbers that is not representable lies at least
 // 2^-49 (relative) away from every f32 rounding boundary — write a = A*2^i, b = B*2^j, boundary (2M+1)*2^(k-1) with 24-bit
 // A, B, M: the difference is a non-zero integer multiple of a power of two over B — so the f64 value rounds to f32 exactly
@@ -52,11 +52,9 @@ DEV f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
 __device__ __attribute__((noinline)) f3 div3_ieee(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }  // the rare path, kept out of line
 DEV f3 operator/(f3 a, float s) {
   const double ds = (double)s;
-  double r = __builtin_amdgcn_rcp(ds);
-  double e = __builtin_fma(-ds, r, 1.0);
-  r = __builtin_fma(e, r, r);
-  e = __builtin_fma(-ds, r, 1.0);
-  r = __builtin_fma(e, r, r);
+  double r = __builtin_amdgcn_rcp(ds);  // 2^-24.4
+  const double e = __builtin_fma(-ds, r, 1.0);
+  r = __builtin_fma(r, __builtin_fma(e, e, e), r);  // r (1 + e + e^2): the residual drops to e^3 = 2^-73, what is left is the rounding
   f3 q = mk3((float)((double)a.x * r), (float)((double)a.y * r), (float)((double)a.z * r));
   constexpr int kDenorm = 0x090, kZeroInfNan = 0x267;  // v_cmp_class masks: +-denormal; +-0, +-inf, sNaN, qNaN
   if (__builtin_amdgcn_class(s, kZeroInfNan) | __builtin_amdgcn_class(q.x, kDenorm) | __builtin_amdgcn_class(q.y, kDenorm) | __builtin_amdgcn_class(q.z, kDenorm))
