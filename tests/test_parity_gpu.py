@@ -493,3 +493,24 @@ def test_render_frame_render_ahead_is_invisible(ctx, pkg, oracle, monkeypatch):
     for f in range(30, 40):
         ctx.render_frame(u(f, 0, v2))
     assert_same_bits(ctx.read_framebuffer(), expect(range(30, 40), v2, max_bounces=3), "after clear")
+
+
+def test_auto_batch_shrinks_when_memory_is_short(pkg, oracle, monkeypatch):
+    """With the automatic frames-in-flight budget, an allocation failure halves the batch instead of failing the render
+    (PTMI_TEST_ALLOC_LIMIT makes every device allocation above 256 MB fail: 512 frames of 256x256 need 600 MB per state array,
+    so the batch shrinks 512 -> 256 -> 128).  Same image as always; an explicit frames_in_flight still fails loudly."""
+    monkeypatch.setenv("PTMI_TEST_ALLOC_LIMIT", str(256 << 20))
+    b = pkg.scenes.golden_buffers("c1")
+    view = cornell_view(pkg)
+    with pkg.Context(0) as ctx:
+        ctx.upload_scene(b)
+        ctx.set_params(max_bounces=3)
+        ctx.resize(256, 256)
+        ctx.render(view, 1, 512)
+        got = ctx.read_framebuffer()
+        assert ctx.stats()["frames"] == 512
+        ctx.set_params(max_bounces=3, frames_in_flight=512)
+        with pytest.raises(pkg.PtmiError):
+            ctx.render(view, 1, 512)
+    want, _ = oracle.render(b, 256, 256, view, 1, 512, max_bounces=3, pixel_range=(256 * 100, 256 * 100 + 512), threads=8)  # 512 pixels: few threads
+    assert_same_bits(got.reshape(-1, 4)[256 * 100:256 * 100 + 512], want.reshape(-1, 4)[256 * 100:256 * 100 + 512], "two rows of the 512-frame image")

@@ -28,6 +28,8 @@ struct DBuf {
     p = nullptr;
     cap = 0;
     if (bytes == 0) return hipSuccess;
+    if (const char* lim = getenv("PTMI_TEST_ALLOC_LIMIT"))  // tests: pretend the board is smaller
+      if (bytes > strtoull(lim, nullptr, 10)) return hipErrorOutOfMemory;
     hipError_t e = hipMalloc(&p, bytes);
     if (e == hipSuccess) cap = bytes;
     return e;
@@ -401,6 +403,9 @@ int ensure_paths(ptmi_ctx* c, size_t npaths, int n_ctl, bool need_pixsum) {
     // A queue holds at most `npaths` paths plus the holes of k_shade's output regions: at most one region per block
     // (region <= slots/grid/16 rounded up to 512) — 1/8 of the paths plus 1024 slots per possible block is ample.
     const size_t slots = npaths + npaths / 8 + (size_t)c->num_cus * 8 * 1024;
+    c->path_cap = 0;  // a failed allocation below leaves some buffers released: nothing may be assumed allocated then
+    c->slot_cap = 0;
+    c->pixsum_alloc = false;
     for (int k = 0; k < 2; k++) {
       HIP_TRY(c, c->d_q0[k].ensure(slots * 16));
       HIP_TRY(c, c->d_q1[k].ensure(slots * 16));
@@ -841,6 +846,10 @@ int ptmi_render(ptmi_ctx* c, const float* view16, uint32_t first_frame, uint32_t
   for (uint32_t done = 0; done < n_frames;) {
     uint32_t nb = std::min(F, n_frames - done);
     r = render_batch(c, view16, first_frame + done, (int)nb, 0);
+    if (r == PTMI_ERR_NO_MEMORY && nb > 1 && c->prm.frames_in_flight <= 0) {
+      F = std::max<uint32_t>(1, nb / 2);  // the automatic budget did not fit this board (or what is left of it): halve and retry
+      continue;
+    }
     if (r) return r;
     done += nb;
   }
