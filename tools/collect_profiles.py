@@ -40,6 +40,26 @@ for w in ("c2", "c3", "c4", "c5"):
     shutil.copy(os.path.join(REL, "bench_%s.json" % w), os.path.join(PROF, "%s_%s_bench.json" % (tag, w)))
 for w in ("c2", "c3"):
     shutil.copy(os.path.join(REL, "kernel_stats_%s.csv" % w), os.path.join(PROF, "%s_%s_kernel_stats.csv" % (tag, w)))
+for w in ("c2", "c4"):
+    src = os.path.join(REL, "pmc_valu_%s.json" % w)
+    if os.path.exists(src):
+        v = json.load(open(src))
+        out = {"_note": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU over "
+                        "`python bench.py --workload %s%s --steps 1 --warmup 0 --cpu-seconds 0` (timed pass + counted pass). SQ_BUSY_CYCLES is summed over the "
+                        "32 shader engines; a wave64 VALU instruction occupies its SIMD for 4 cycles; active lanes = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)."
+                        % (w, " --spp 64" if w == "c4" else "")}
+        for name, c in v.items():
+            if not name.startswith("k_"):
+                continue
+            rec = dict(c)
+            if c.get("SQ_BUSY_CYCLES") and c.get("ms_total"):
+                clk = c["SQ_BUSY_CYCLES"] / 32.0 / (c["ms_total"] * 1e-3)
+                rec["clock_ghz"] = clk / 1e9
+                rec["valu_busy_frac"] = c.get("SQ_INSTS_VALU", 0.0) * 4.0 / (1024.0 * c["SQ_BUSY_CYCLES"] / 32.0)
+            if c.get("SQ_ACTIVE_INST_VALU"):
+                rec["active_lane_frac"] = c.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+            out[name] = rec
+        json.dump(out, open(os.path.join(PROF, "%s_pmc_valu_%s.json" % (tag, w)), "w"), indent=1)
 for w in ("c2", "c3", "c4", "c5"):
     d = json.loads(open(os.path.join(PROF, "%s_%s_bench.json" % (tag, w))).read())
     r = d["roofline"]

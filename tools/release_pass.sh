@@ -18,4 +18,8 @@ for w in c2 c3; do
     cp gpurun_out/pmc_${w}_$c.json $R/
   done
 done
+# what bounds the kernels: VALU instruction counts, busy cycles, active lanes (cited in DESIGN.md section 5)
+tools/pmc.sh valu_c2 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" --workload c2 --steps 1 --warmup 0 --cpu-seconds 0 > /dev/null || exit 1
+tools/pmc.sh valu_c4 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" --workload c4 --spp 64 --steps 1 --warmup 0 --cpu-seconds 0 > /dev/null || exit 1
+cp gpurun_out/pmc_valu_c2.json gpurun_out/pmc_valu_c4.json $R/
 echo release pass done
