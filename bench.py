@@ -6,13 +6,30 @@ A "step" is one full render of the workload: clear the accumulation buffer, trac
 frames (frame numbers 1..spp, resetBuffer = 0), and — for N > 1 — sum-reduce the per-rank framebuffers
 to rank 0.  Scene, BVH and path buffers are resident in HBM before the timed region.
 Rays are counted exactly (one per hitScene invocation) by the device.
-N > 1 is weak scaling: pixels are sharded across ranks in tiles and spp is multiplied by N, so the
-rays per GPU stay fixed.
+N > 1: pixels are sharded across ranks in tiles; `--scaling weak` (default) multiplies spp by N so that the rays
+per GPU stay fixed, `--scaling strong` keeps the total spp (BASELINE configs[3]/[4] are fixed totals).
+
+What the line carries besides the contract's fields (N = 1):
+  roofline      for the kernel with the largest share of the timed step: its launch time is measured live with HIP events
+                on the context's stream inside the timed region; VALU-busy cycles and HBM bytes per launch come from
+                rocprofv3 --pmc passes that THIS run makes over the same workload before it touches the GPU itself
+                (separate passes for the SQ counters, FETCH_SIZE and WRITE_SIZE; gfx950 correction 2*FETCH_SIZE + WRITE_SIZE).
+                frac = achieved / peak <= 1 in the unit of the bound it names; the per-kernel table is next to it.
+  configs       the other single-GPU configuration north_star sets its target on (configs[2], 871,414 triangles),
+                timed by the same procedure (2 steps).
+  setup_ms      scene set-up: BVH build (host threads / GPU / the reference's algorithm in single-threaded JavaScript),
+                validation + digests + upload.
+  cpu_baseline  the CPU oracle on all host cores and on one, plus the JavaScript BVH build.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -22,12 +39,320 @@ import numpy as np  # noqa: E402
 
 import __graft_entry__ as entry  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+N_SIMD = 1024           # 256 CUs x 4 SIMDs
+REF_DRAGON_MPATHS = 33.5  # reference/benchmarks.txt:18-20: 62 fps x 900x600 px, 1 path per pixel and frame (derived in BASELINE.md §1)
+KERNELS = ("k_generate", "k_bvh", "k_shade", "k_accumulate")
+TIMING_MODE = {"k_bvh": 2, "k_shade": 3, "k_generate": 4, "k_accumulate": 5}
+MS_KEY = {"k_bvh": "bvh_ms", "k_shade": "shade_ms", "k_generate": "generate_ms", "k_accumulate": "accumulate_ms"}
+LAUNCH_KEY = {"k_bvh": "intersect_launches", "k_shade": "shade_launches", "k_generate": "generate_launches", "k_accumulate": "accumulate_launches"}
+SPP = {"c2": 64, "c3": 256, "c4": 512, "c5": 1024}
 
 
 def alg_bytes(st):
     """SURVEY.md §8d algorithmic bytes of hitScene in the reference's layouts."""
     return 48 * st["node_visits"] + 96 * st["tri_tests"] + 64 * st["mat_fetches"] + 32 * st["sphere_tests"] + 80 * st["quad_tests"]
+
+
+class TimedNative:
+    """NativeHost that remembers how long the BVH build took and what it was given (for the other builders' timings)."""
+
+    def __init__(self, native):
+        self.native, self.bvh_ms, self.boxes = native, 0.0, None
+
+    def build_bvh(self, bmin, bmax, prim_type=2):
+        t = time.perf_counter()
+        r = self.native.build_bvh(bmin, bmax, prim_type)
+        self.bvh_ms += (time.perf_counter() - t) * 1e3
+        self.boxes = (np.ascontiguousarray(bmin, np.float64), np.ascontiguousarray(bmax, np.float64))
+        return r
+
+    def __getattr__(self, k):
+        return getattr(self.native, k)
+
+
+def make_workload(pkg, name, args):
+    """Scene buffers + parameters of one BASELINE configuration."""
+    wl = {"name": name, "cam": "cornell", "extra": {}, "W": args.width, "H": args.height, "bounces": args.bounces, "setup": {}}
+    sah = args.bvh == "sah"
+    t0 = time.perf_counter()
+    native = TimedNative(pkg.ptmi.NativeHost())
+    if name == "c2":
+        if sah:
+            raise SystemExit("--bvh sah needs a workload built through the Scene API (c3, c4, c5)")
+        wl["buffers"] = pkg.scenes.golden_buffers("c2")  # reference-generated buffers of configs[1] (tests/golden)
+        wl["label"], wl["stack"] = "configs[1]: Cornell + monkey_968.obj (967 tris)", args.stack_size or 20
+    elif name == "c3":
+        wl["buffers"] = pkg.scenes.c3_scene().buffers(native=native, sah=sah)  # procedural stand-in, 871,414 tris
+        wl["label"], wl["stack"] = "configs[2]: Cornell + dragon-class mesh (871,414 tris, procedural stand-in for stanfordDragon.obj)", args.stack_size or 24
+    elif name == "c4":
+        wl["buffers"] = pkg.scenes.c4_scene().buffers(native=native, sah=sah)
+        wl["label"], wl["stack"], wl["cam"] = "configs[3]: sponza-class interior (262,267 tris, procedural stand-in for sponzaAtrium.obj), camera inside", args.stack_size or 24, "interior"
+    else:
+        wl["buffers"] = pkg.scenes.c5_scene().buffers(native=native, sah=sah)
+        wl["label"], wl["stack"], wl["extra"] = "configs[4]: Cornell + buddha-class glass mesh (1,087,716 tris, procedural stand-in for buddha.obj), importance sampling", args.stack_size or 24, dict(importance_sampling=1)
+        if wl["bounces"] == 8:
+            wl["bounces"] = 16
+    wl["view"] = pkg.scenes.camera_view(*pkg.scenes.CAMERAS[wl["cam"]])
+    wl["native"] = native
+    if name != "c2":
+        wl["setup"]["host_scene_and_packing_ms"] = (time.perf_counter() - t0) * 1e3 - native.bvh_ms  # Python mirror of lib/scene.js (+ the procedural mesh): not the product
+        wl["setup"]["bvh_build_native_host_ms"] = native.bvh_ms
+    return wl
+
+
+def make_context(pkg, wl, device, args):
+    ctx = pkg.Context(device)
+    t = time.perf_counter()
+    ctx.upload_scene(wl["buffers"])
+    ctx.set_params(max_bounces=wl["bounces"], frames_in_flight=args.frames_in_flight, stack_size=wl["stack"], **wl["extra"])
+    ctx.resize(wl["W"], wl["H"])
+    ctx.prepare()  # validation + digests + upload, synchronous
+    wl["setup"]["upload_validate_digests_ms"] = (time.perf_counter() - t) * 1e3
+    return ctx
+
+
+# ---------------------------------------------------------------------------------------------------- rocprofv3 passes
+PMC_PASSES = (
+    ("sq", "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY"),
+    ("fetch", "FETCH_SIZE"),
+    ("write", "WRITE_SIZE"),
+)
+
+
+def pmc_child(args):
+    """Runs under rocprofv3 (started by pmc_passes): the same workload, one warm-up step and one profiled-as-everything step,
+    timed-pass kernels only.  No torch, no oracle: nothing but the context."""
+    pkg = entry._load_pkg()
+    wl = make_workload(pkg, args.workload, args)
+    ctx = make_context(pkg, wl, 0, args)
+    spp = args.spp or SPP[args.workload]
+    for _ in range(2):
+        ctx.clear()
+        ctx.render(wl["view"], 1, spp)
+        ctx.synchronize()
+    ctx.close()
+
+
+def pmc_passes(args, workload, log):
+    """Per-kernel counter sums of the timed-pass kernels of `workload`, from three rocprofv3 --pmc runs of this script in child mode.
+    Returns {kernel: {counter: value per launch, 'launches': n, 'pmc_ms_per_launch': ...}} or (None, reason)."""
+    rocprof = shutil.which("rocprofv3")
+    if not rocprof:
+        return None, "rocprofv3 not on PATH"
+    out = {}
+    t_all = time.perf_counter()
+    for tag, ctrs in PMC_PASSES:
+        d = tempfile.mkdtemp(prefix="ptmi_pmc_%s_" % tag, dir="/tmp")
+        cmd = [rocprof, "--pmc"] + ctrs.split() + ["--output-format", "csv", "-d", d, "-o", "run", "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
+                                                  "--workload", workload, "--width", str(args.width), "--height", str(args.height), "--bounces", str(args.bounces),
+                                                  "--frames-in-flight", str(args.frames_in_flight), "--bvh", args.bvh, "--stack-size", str(args.stack_size),
+                                                  "--spp", str(args.spp if workload == args.workload else 0)]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=args.pmc_timeout)
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, "rocprofv3 pass '%s' timed out" % tag
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            log.append(r.stdout[-1500:])
+            shutil.rmtree(d, ignore_errors=True)
+            return None, "rocprofv3 pass '%s' failed (rc %d)" % (tag, r.returncode)
+        seen = {}
+        for f in files:
+            for row in csv.DictReader(open(f)):
+                k = row["Kernel_Name"].replace("ptmi::", "").replace("void ", "").split("(")[0].strip().split("<")[0]
+                if k not in KERNELS:
+                    continue
+                rec = out.setdefault(k, {})
+                rec[row["Counter_Name"]] = rec.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                seen.setdefault((tag, k), {})[row["Dispatch_Id"]] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
+        for (t, k), disp in seen.items():
+            out[k]["launches_" + t] = len(disp)
+            out[k]["pmc_ms_" + t] = sum(disp.values())
+        shutil.rmtree(d, ignore_errors=True)
+    out["_seconds"] = time.perf_counter() - t_all
+    return out, None
+
+
+def kernel_table(split, steps_in_split, pmc):
+    """Per-kernel figures: live ms per step (HIP events, uncounted kernels), and — from this run's PMC passes — VALU-busy
+    fraction, HBM bytes per launch, wait fraction, active lanes."""
+    tab = {}
+    total = sum(split[MS_KEY[k]] for k in KERNELS) or 1.0
+    for k in KERNELS:
+        ms, n = split[MS_KEY[k]] / steps_in_split, max(split[LAUNCH_KEY[k]], 1) / steps_in_split
+        e = {"ms_per_step": ms, "launches_per_step": n, "share_of_kernel_time": split[MS_KEY[k]] / total, "avg_launch_ms": ms / n if n else None}
+        p = (pmc or {}).get(k)
+        if p and p.get("launches_sq"):
+            L = p["launches_sq"]
+            cyc = p["SQ_BUSY_CYCLES"] / 32.0 / L                      # kernel cycles per launch (the counter is summed over 8 XCDs x 4 SEs)
+            clock = cyc / (p["pmc_ms_sq"] / L * 1e-3) if p["pmc_ms_sq"] else 0.0
+            busy = 4.0 * p["SQ_ACTIVE_INST_VALU"] / N_SIMD / L        # SQ_ACTIVE_INST_* count quad-cycles; average per SIMD
+            live_cyc = (ms / n * 1e-3) * clock if n and clock else cyc
+            e.update({
+                "valu_instr_per_launch": p["SQ_INSTS_VALU"] / L,
+                "valu_busy_frac": min(1.0, busy / live_cyc) if live_cyc else None,
+                "avg_cycles_per_valu_instr": 4.0 * p["SQ_ACTIVE_INST_VALU"] / p["SQ_INSTS_VALU"] if p["SQ_INSTS_VALU"] else None,
+                "wave_wait_frac": p["SQ_WAIT_ANY"] / p["SQ_WAVE_CYCLES"] if p["SQ_WAVE_CYCLES"] else None,
+                "active_lane_frac": p["SQ_THREAD_CYCLES_VALU"] / (64.0 * p["SQ_ACTIVE_INST_VALU"]) if p["SQ_ACTIVE_INST_VALU"] else None,
+                "clock_ghz_in_pmc_pass": clock / 1e9,
+                "pmc_pass_avg_launch_ms": p["pmc_ms_sq"] / L,
+            })
+        if p and p.get("launches_fetch") and p.get("launches_write"):
+            fb = p["FETCH_SIZE"] * 1024.0 / p["launches_fetch"]         # counter unit: KB
+            wb = p["WRITE_SIZE"] * 1024.0 / p["launches_write"]
+            e["hbm_bytes_per_launch"] = 2.0 * fb + wb                    # gfx950: FETCH_SIZE reports half the bytes of wide reads (MI355X_MICROARCH.md, HBM)
+            e["hbm_frac"] = min(1.0, e["hbm_bytes_per_launch"] / (ms / n * 1e-3) / (HBM_PEAK_GBS * 1e9)) if n and ms else None
+        tab[k] = e
+    return tab
+
+
+def roofline_of(tab, dom, timed_ms_per_launch, timed_launches):
+    """The contract's roofline object for the dominant kernel `dom`, in the unit of the bound it actually hits."""
+    e = tab[dom]
+    vf, hf = e.get("valu_busy_frac"), e.get("hbm_frac")
+    r = {"kernel": dom, "avg_launch_ms": timed_ms_per_launch, "launches": timed_launches, "share_of_kernel_time": e["share_of_kernel_time"],
+         "traffic": e.get("hbm_bytes_per_launch")}
+    if vf is None and hf is None:
+        r.update({"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None})
+        return r
+    # re-base the fractions on the launch time measured inside the timed region
+    scale = (e["avg_launch_ms"] / timed_ms_per_launch) if (timed_ms_per_launch and e["avg_launch_ms"]) else 1.0
+    vf = min(1.0, vf * scale) if vf is not None else None
+    hf = min(1.0, hf * scale) if hf is not None else None
+    if hf is not None and (vf is None or hf > vf):
+        gbs = e["hbm_bytes_per_launch"] / (timed_ms_per_launch * 1e-3) / 1e9
+        r.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
+    else:
+        rate = e["valu_instr_per_launch"] / (timed_ms_per_launch * 1e-3) / 1e9
+        r.update({"bound": "valu_issue", "achieved": rate, "peak": rate / vf if vf else None, "unit": "G wave-instr/s", "frac": vf,
+                  "peak_definition": "the rate at which this kernel's own instruction mix issues when no SIMD is ever idle: instructions / "
+                                     "(4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs) x clock; the mix averages %.2f cycles per wave64 instruction "
+                                     "(profiles/valu_peak.json: 2 for f32 fma/mul/add/mov, 4 for min/max/cmp/shift/cvt/f64/packed, 8 for f32 transcendentals, 16 for v_rcp_f64)"
+                                     % (e.get("avg_cycles_per_valu_instr") or 0.0)})
+    if max(vf or 0.0, hf or 0.0) < 0.5:
+        r["bound_note"] = "neither the VALU nor HBM is busy half the time: the kernel waits on memory latency (wave_wait_frac %.2f)" % (e.get("wave_wait_frac") or 0.0)
+    r["valu_busy_frac"], r["hbm_frac"] = vf, hf
+    return r
+
+
+# ---------------------------------------------------------------------------------------------------- one GPU measurement
+def measure(pkg, torch, pdist, ctx, wl, spp, steps, warmup, world, rank, fb_t, rehearse):
+    view = wl["view"]
+
+    def step():
+        ctx.clear()
+        ctx.render(view, 1, spp)
+        ctx.synchronize()
+        if world > 1 and rehearse:
+            host = fb_t.cpu()
+            pdist.reduce_framebuffer(host, 0)
+            fb_t.copy_(host)
+            torch.cuda.synchronize()
+        elif world > 1:
+            pdist.reduce_framebuffer(fb_t, 0)
+            torch.cuda.synchronize()  # the reduce runs on torch's stream; the next clear runs on the context's
+
+    for _ in range(warmup):
+        step()
+    # per-kernel split of one step (HIP events around every launch; the kernels are the timed ones, not the counted variants)
+    ctx.synchronize()
+    ctx.reset_stats()
+    ctx.set_timing(1)
+    step()
+    split = ctx.stats()
+    ctx.set_timing(0)
+    dom = max(KERNELS, key=lambda k: split[MS_KEY[k]])
+    # the timed region: events only around the dominant kernel (every event is a stream marker)
+    ctx.reset_stats()
+    ctx.set_timing(TIMING_MODE[dom])
+    if torch is not None:
+        torch.cuda.synchronize()
+    pdist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.synchronize()
+    if torch is not None:
+        torch.cuda.synchronize()
+    pdist.barrier()
+    dt = time.perf_counter() - t0
+    st = ctx.stats()
+    ctx.set_timing(0)
+    # exact work counters of one step (counted variants of the same kernels, untimed)
+    ctx.reset_stats()
+    ctx.set_counters(True)
+    ctx.clear()
+    ctx.render(view, 1, spp)
+    cst = ctx.stats()
+    ctx.set_counters(False)
+    assert cst["rays"] * steps == st["rays"], "ray count differs between the counted and the timed pass"
+    return {"dt": dt, "st": st, "split": split, "cst": cst, "dom": dom}
+
+
+def cpu_baseline(pkg, wl, spp, args):
+    from oracle import ptm_oracle
+
+    W, H, view, buffers = wl["W"], wl["H"], wl["view"], wl["buffers"]
+    kw = dict(max_bounces=wl["bounces"], stack_size=wl["stack"], **wl["extra"])
+    cores = min(ptm_oracle.max_threads(), args.cpu_threads)
+
+    def sample(threads, seconds, rows):
+        # rows = how many image rows the probe frame covers (the single-thread sample is bounded by a pixel window)
+        pr = None if rows >= H else (0, rows * W)
+        t = time.perf_counter()
+        _, ost = ptm_oracle.render(buffers, W, H, view, 1, 1, threads=threads, pixel_range=pr, **kw)
+        one = time.perf_counter() - t
+        frames = int(max(1, min(spp, seconds / max(one, 1e-3))))
+        t = time.perf_counter()
+        _, ost = ptm_oracle.render(buffers, W, H, view, 1, frames, threads=threads, pixel_range=pr, **kw)
+        cdt = time.perf_counter() - t
+        what = "same scene and camera, %dx%d%s, frames 1..%d of %d (%d rays), scalar f32 oracle%s" % (
+            W, H, "" if pr is None else ", pixel rows 0..%d" % (rows - 1), frames, spp, ost["rays"], " with OpenMP over pixels" if threads > 1 else ", one thread")
+        return ost["rays"] / cdt / 1e6, what
+
+    v, what = sample(cores, args.cpu_seconds, H)
+    out = {"value": v, "unit": "Mrays/s", "cores": cores, "kind": "port", "sample": what}
+    v1, what1 = sample(1, max(2.0, args.cpu_seconds * 0.6), max(1, H // 16))
+    out["single_thread"] = {"value": v1, "unit": "Mrays/s", "cores": 1, "sample": what1}
+    return out
+
+
+def js_bvh_build(native, n_hint=None):
+    """The reference's one CPU loop — the median-split BVH build (lib/BVH/bvhNode.js:28-73) — as single-threaded JavaScript under
+    Node on this box (js/bvh_time.mjs: the shipped restatement, byte-identical output to the reference's, tests/test_host_buffers.py)."""
+    node = shutil.which("node") or shutil.which("nodejs")
+    if not node or native.boxes is None:
+        return None
+    a, b = native.boxes
+    with tempfile.NamedTemporaryFile(suffix=".f64", delete=False, dir="/tmp") as f:
+        f.write(a.tobytes())
+        f.write(b.tobytes())
+    try:
+        r = subprocess.run([node, "--max-old-space-size=8192", os.path.join(ROOT, "webgpu-path-tracer_amd", "js", "bvh_time.mjs"), f.name], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        if r.returncode != 0:
+            return {"error": r.stderr[-300:]}
+        js = json.loads(r.stdout)
+        return {"ms": js["ms"], "primitives": js["n"], "node": js["node"], "threads": 1, "host_cpus": os.cpu_count(),
+                "reference": "lib/BVH/bvhNode.js:28-73; benchmarks.txt:19 quotes 4483 ms for the 297,972-triangle dragon in a browser"}
+    finally:
+        os.remove(f.name)
+
+
+def c2_mesh_boxes(pkg, native):
+    """Boxes of configs[1]'s mesh for the build timings: the golden triangles, padded as lib/BVH/AABB.js does (through the host mirror)."""
+    try:
+        sc = pkg.scenes.c2_scene() if hasattr(pkg.scenes, "c2_scene") else None
+    except Exception:
+        sc = None
+    if sc is None:
+        return False
+    try:
+        sc.buffers(native=native)
+        return native.boxes is not None
+    except Exception:
+        return False
 
 
 def main():
@@ -40,7 +365,8 @@ def main():
                          "c4 = configs[3] sponza-class interior; c5 = configs[4] buddha-class + glass + importance sampling (use --width 3840 --height 2160)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=0, help="progressive frames per step and per GPU (0 = the config's: 64 for c2, 256 for c3)")
+    ap.add_argument("--spp", type=int, default=0, help="progressive frames per step (0 = the config's: 64 for c2, 256 for c3, 512 for c4, 1024 for c5); per GPU with --scaling weak, in total with strong")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: weak = spp x N (fixed rays per GPU), strong = fixed total spp (fixed total rays)")
     ap.add_argument("--stack-size", type=int, default=0)
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--frames-in-flight", type=int, default=0)
@@ -51,8 +377,28 @@ def main():
                     help="N>1 on ONE GPU for rehearsal: ranks share cuda:0, the framebuffer reduce goes through gloo on host copies "
                          "(RCCL wants one device per rank); numbers from this mode are not bench results")
     ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the cpu_baseline (the 1-GPU box's CPU share)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline's all-cores sample (0 = skip the CPU legs)")
+    ap.add_argument("--pmc", default="auto", choices=["auto", "off"], help="auto = rocprofv3 --pmc passes over the workload before the timed run (N = 1 only)")
+    ap.add_argument("--pmc-timeout", type=float, default=240.0)
+    ap.add_argument("--extra-configs", default="auto", choices=["auto", "off"], help="auto = append the configs[2] (871k-triangle) run to the line (N = 1, default workload only)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.pmc_child:
+        pmc_child(args)
+        return
+
+    rank_env, world_env = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    solo = world_env == 1 and max(args.gpus, 1) == 1
+    extra_c3 = solo and args.extra_configs == "auto" and args.workload == "c2"
+
+    # rocprofv3 passes first: child processes, before this process has touched the GPU
+    pmc, pmc_note, pmc_log = {}, {}, []
+    if solo and args.pmc == "auto":
+        for w in [args.workload] + (["c3"] if extra_c3 else []):
+            pmc[w], why = pmc_passes(args, w, pmc_log)
+            if why:
+                pmc_note[w] = why
 
     import torch
 
@@ -66,158 +412,104 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     torch.cuda.set_device(local)
 
-    W, H = args.width, args.height
-    cam, extra = "cornell", {}
-    if args.spp <= 0:
-        args.spp = {"c2": 64, "c3": 256, "c4": 512, "c5": 1024}[args.workload]
-    if args.workload == "c5" and args.bounces == 8:
-        args.bounces = 16
-    spp = args.spp * world
-    sah = args.bvh == "sah"
-    if sah and args.workload == "c2":
-        raise SystemExit("--bvh sah needs a workload built through the Scene API (c3, c4, c5)")
-    if args.workload == "c2":
-        buffers = pkg.scenes.golden_buffers("c2")  # reference-generated buffers of configs[1] (tests/golden)
-        label, stack = "configs[1]: Cornell + monkey_968.obj (967 tris)", args.stack_size or 20
-    elif args.workload == "c3":
-        buffers = pkg.scenes.c3_scene().buffers(native=pkg.ptmi.NativeHost(), sah=sah)  # procedural stand-in, 871,414 tris
-        label, stack = "configs[2]: Cornell + dragon-class mesh (871,414 tris, procedural stand-in for stanfordDragon.obj)", args.stack_size or 24
-    elif args.workload == "c4":
-        buffers = pkg.scenes.c4_scene().buffers(native=pkg.ptmi.NativeHost(), sah=sah)
-        label, stack, cam = "configs[3]: sponza-class interior (262,267 tris, procedural stand-in for sponzaAtrium.obj), camera inside", args.stack_size or 24, "interior"
-    else:
-        buffers = pkg.scenes.c5_scene().buffers(native=pkg.ptmi.NativeHost(), sah=sah)
-        label, stack, extra = "configs[4]: Cornell + buddha-class glass mesh (1,087,716 tris, procedural stand-in for buddha.obj), importance sampling", args.stack_size or 24, dict(importance_sampling=1)
-    view = pkg.scenes.camera_view(*pkg.scenes.CAMERAS[cam])
-    ctx = pkg.Context(local)
-    ctx.upload_scene(buffers)
-    ctx.set_params(max_bounces=args.bounces, frames_in_flight=args.frames_in_flight, stack_size=stack, **extra)
-    ctx.resize(W, H)
-    fb_t = None
-    if world > 1:
-        fb_t = torch.zeros(H * W * 4, dtype=torch.float32, device="cuda")
-        ctx.bind_framebuffer(fb_t.data_ptr(), fb_t.numel() * 4)
-        ctx.set_shard(rank, world, pdist.TILE_PIXELS)
+    def run_workload(name, steps, warmup, spp_arg):
+        wl = make_workload(pkg, name, args)
+        per = spp_arg or SPP[name]
+        spp = per * world if args.scaling == "weak" else per
+        ctx = make_context(pkg, wl, local, args)
+        fb_t = None
+        if world > 1:
+            fb_t = torch.zeros(wl["H"] * wl["W"] * 4, dtype=torch.float32, device="cuda")
+            ctx.bind_framebuffer(fb_t.data_ptr(), fb_t.numel() * 4)
+            ctx.set_shard(rank, world, pdist.TILE_PIXELS)
+        m = measure(pkg, torch, pdist, ctx, wl, spp, steps, warmup, world, rank, fb_t, args.rehearse_gloo)
+        return wl, ctx, spp, per, m
 
-    def step():
-        ctx.clear()
-        ctx.render(view, 1, spp)
-        ctx.synchronize()
-        if world > 1 and args.rehearse_gloo:
-            host = fb_t.cpu()
-            pdist.reduce_framebuffer(host, 0)
-            fb_t.copy_(host)
-            torch.cuda.synchronize()
-        elif world > 1:
-            pdist.reduce_framebuffer(fb_t, 0)
-            torch.cuda.synchronize()  # the reduce runs on torch's stream; the next clear runs on the context's
-
-    for _ in range(args.warmup):
-        step()
-    ctx.synchronize()
-    ctx.reset_stats()
-    ctx.set_timing(2)  # HIP events around the dominant kernel (k_bvh) only: every event is a stream marker
-    torch.cuda.synchronize()
-    pdist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    pdist.barrier()
-    dt = time.perf_counter() - t0
-    st = ctx.stats()
-    ctx.set_timing(0)
-
-    dt_max = pdist.all_reduce_scalar(dt, "max")
+    wl, ctx, spp, per, m = run_workload(args.workload, args.steps, args.warmup, args.spp)
+    st, cst, dom = m["st"], m["cst"], m["dom"]
+    dt_max = pdist.all_reduce_scalar(m["dt"], "max")
     rays_all = pdist.all_reduce_scalar(st["rays"], "sum")
     paths_all = pdist.all_reduce_scalar(st["paths"], "sum")
 
-    # exact algorithmic bytes of one step (counted variant of the same kernels, untimed)
-    ctx.reset_stats()
-    ctx.set_counters(True)
-    ctx.set_timing(1)  # per-kernel split, outside the timed region
-    ctx.clear()
-    ctx.render(view, 1, spp)
-    cst = ctx.stats()
-    ctx.set_counters(False)
-    ctx.set_timing(0)
-    assert cst["rays"] * args.steps == st["rays"], "ray count differs between the counted and the timed pass"
-    bytes_total = alg_bytes(cst) * args.steps  # all of hitScene (k_prims + k_bvh)
-    # the dominant kernel is the BVH traversal; its share of the algorithmic bytes (reference layouts):
-    bvh_bytes = (48 * cst["bvh_node_visits"] + 96 * cst["tri_tests"] + 64 * cst["bvh_mat_fetches"]) * args.steps
-    launches = max(st["intersect_launches"], 1)
-    bvh_s = st["bvh_ms"] / 1e3
-    achieved = bvh_bytes / bvh_s / 1e9 if bvh_s > 0 else 0.0
-    # all of hitScene's algorithmic bytes (part 1 runs inside k_generate / k_shade) over the whole render of the counted pass
-    hit_scene = (bytes_total / args.steps) / (cst["render_ms"] / 1e3) / 1e9 if cst["render_ms"] > 0 else 0.0
-    traffic = None
-    prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(prof):
-        try:
-            traffic = json.load(open(prof)).get(args.workload, {}).get("k_bvh_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    def describe(wl, spp, per, m, steps, rays, paths, dt, pm):
+        """value / roofline / kernel table of one measured workload."""
+        st, cst, dom = m["st"], m["cst"], m["dom"]
+        tab = kernel_table(m["split"], 1, pm)
+        n_dom = max(st[LAUNCH_KEY[dom]], 1)
+        roof = roofline_of(tab, dom, st[MS_KEY[dom]] / n_dom, n_dom)
+        hit_scene_gbs = alg_bytes(cst) / (m["split"]["render_ms"] / 1e3) / 1e9 if m["split"]["render_ms"] > 0 else None
+        roof["algorithmic_hit_scene_gbs_informational"] = hit_scene_gbs  # SURVEY §8d reference-layout bytes / render time: cache-oblivious, NOT a fraction of HBM peak
+        roof["work_per_ray"] = {k: cst[k] / max(cst["rays"], 1) for k in ("node_visits", "bvh_node_visits", "tri_tests", "quad_tests", "sphere_tests", "mat_fetches")}
+        roof["kernels"] = tab
+        return {
+            "value": rays / dt / 1e6, "ms_per_step": dt / steps * 1e3, "rays_per_step": rays / steps, "mpaths_per_s": paths / dt / 1e6,
+            "workload": "%s, %dx%d, %d spp%s, %d bounces, stack_size %d%s" % (
+                wl["label"], wl["W"], wl["H"], spp, (" (%d per GPU x %d)" % (per, world) if world > 1 and args.scaling == "weak" else ""), wl["bounces"], wl["stack"],
+                ", SAH BVH (opt-in)" if args.bvh == "sah" else ""),
+            "roofline": roof,
+        }
 
     out = None
     if rank == 0:
+        d = describe(wl, spp, per, m, args.steps, rays_all, paths_all, dt_max, pmc.get(args.workload))
         out = {
             "metric": "Mrays/s at 1080p, 8 bounces; achieved HBM GB/s vs roofline",
-            "value": rays_all / dt_max / 1e6,
+            "value": d["value"],
             "unit": "Mrays/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt_max / args.steps * 1e3,
+            "ms_per_step": d["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s, %dx%d, %d spp per GPU (%d total), %d bounces, stack_size %d%s" % (label, W, H, args.spp, spp, args.bounces, stack, ", SAH BVH (opt-in)" if sah else ""),
-                "rays_per_step": rays_all / args.steps,
-                "mpaths_per_s": paths_all / dt_max / 1e6,
-                "parallelism": "pixel tiles x%d + 1 RCCL reduce" % world if world > 1 else "1 GPU",
+                "workload": d["workload"],
+                "rays_per_step": d["rays_per_step"],
+                "mpaths_per_s": d["mpaths_per_s"],
+                "parallelism": ("pixel tiles x%d + 1 RCCL reduce" % world) if world > 1 else "1 GPU",
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_bvh",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_launch": bvh_bytes / launches,
-                "avg_launch_ms": st["bvh_ms"] / launches,
-                "launches": launches,
-                "hit_scene_algorithmic_gbs_whole_render": hit_scene,
-                "note": "k_bvh is bound by VALU issue and fetch latency (rocprofv3 PMC: ~66 % VALU busy at ~54 % active lanes on deep trees), not by HBM: "
-                        "algorithmic bytes are reference-layout bytes, most of them served by L2 / Infinity Cache, so frac can exceed 1 (DESIGN.md section 5)",
-                "work_per_ray": {k: cst[k] / max(cst["rays"], 1) for k in ("node_visits", "bvh_node_visits", "tri_tests", "quad_tests", "sphere_tests", "mat_fetches")},
-                "kernel_ms_one_step_counted_pass": {"prims": cst["prims_ms"], "bvh": cst["bvh_ms"], "shade": cst["shade_ms"], "other": cst["other_ms"], "render": cst["render_ms"]},
-            },
+            "roofline": d["roofline"],
         }
-        if world == 1 and args.cpu_seconds > 0:
-            from oracle import ptm_oracle
-
-            cores = min(ptm_oracle.max_threads(), args.cpu_threads)
-            t = time.perf_counter()
-            _, ost = ptm_oracle.render(buffers, W, H, view, 1, 1, max_bounces=args.bounces, stack_size=stack, threads=cores, **extra)
-            one = time.perf_counter() - t
-            frames = int(max(1, min(args.spp, args.cpu_seconds / max(one, 1e-3))))
-            t = time.perf_counter()
-            _, ost = ptm_oracle.render(buffers, W, H, view, 1, frames, max_bounces=args.bounces, stack_size=stack, threads=cores, **extra)
-            cdt = time.perf_counter() - t
-            out["cpu_baseline"] = {
-                "value": ost["rays"] / cdt / 1e6,
-                "unit": "Mrays/s",
-                "cores": cores,
-                "kind": "port",
-                "sample": "same scene and camera, %dx%d, frames 1..%d of %d (%d rays), scalar f32 oracle with OpenMP over pixels" % (W, H, frames, args.spp, ost["rays"]),
-            }
-        print(json.dumps(out), flush=True)
+        if args.workload in pmc_note:
+            out["roofline"]["pmc_note"] = pmc_note[args.workload]
+        elif pmc.get(args.workload):
+            out["roofline"]["pmc_source"] = "rocprofv3 --pmc passes made by this run (%s), %.0f s" % (" | ".join(c for _, c in PMC_PASSES), pmc[args.workload]["_seconds"])
     ctx.close()
+
+    if rank == 0 and solo:
+        setup = {args.workload: wl["setup"]}
+        if extra_c3:
+            wl3, ctx3, spp3, per3, m3 = run_workload("c3", 2, 1, 0)
+            d3 = describe(wl3, spp3, per3, m3, 2, m3["st"]["rays"], m3["st"]["paths"], m3["dt"], pmc.get("c3"))
+            # the reference's own dragon figure (benchmarks.txt:18-20) is paths/s at its canvas size; both readings of north_star's ">= 10x"
+            d3["vs_baseline"] = d3["mpaths_per_s"] / REF_DRAGON_MPATHS
+            d3["vs_baseline_basis"] = ("Mpaths/s / 33.5 Mpaths/s = the reference's 62 fps x 900x600 px on its 297,972-triangle dragon (benchmarks.txt:18-20; hardware, "
+                                       "bounce cap unstated; derived in BASELINE.md §1, not a published Mrays/s). Rays / 33.5 M (the minimum reading: >= 1 ray per path) = %.0f" % (d3["value"] / REF_DRAGON_MPATHS))
+            if "c3" in pmc_note:
+                d3["roofline"]["pmc_note"] = pmc_note["c3"]
+            # set-up of the 871k-triangle scene, next to the reference's 4,483 ms BVH build of its dragon
+            t = time.perf_counter()
+            ctx3.build_bvh(*wl3["native"].boxes)
+            wl3["setup"]["bvh_build_device_ms"] = (time.perf_counter() - t) * 1e3
+            ctx3.close()
+            if args.cpu_seconds > 0:
+                wl3["setup"]["bvh_build_js_single_thread"] = js_bvh_build(wl3["native"])
+            d3["setup_ms"] = wl3["setup"]
+            out["configs"] = [d3]
+            out["vs_baseline"] = d3["vs_baseline"]
+            out["vs_baseline_basis"] = "configs[0] of this line (the dragon-class run): " + d3["vs_baseline_basis"]
+        out["setup_ms"] = setup[args.workload]
+        if args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(pkg, wl, spp, args)
+            if extra_c3 and out["configs"][0]["setup_ms"].get("bvh_build_js_single_thread"):
+                out["cpu_baseline"]["bvh_build_js_ms"] = out["configs"][0]["setup_ms"]["bvh_build_js_single_thread"]
+            elif args.workload != "c2":
+                out["cpu_baseline"]["bvh_build_js_ms"] = js_bvh_build(wl["native"])
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
 

@@ -8,8 +8,11 @@
  * reference call it replaces.  All buffers use the reference's own byte layouts;
  * the library copies on upload and never keeps caller pointers.
  *
- * A context is single-caller (not thread-safe) and bound to ONE GPU; multi-GPU = one process (or one
- * context) per GPU with disjoint pixel tiles (ptmi_set_shard) and one sum-reduce of the framebuffers.
+ * A context is single-caller (not thread-safe).  Multi-GPU, two ways, both = disjoint pixel tiles per GPU and ONE sum-reduce
+ * of the accumulation buffers: (a) ptmi_create_multi — one context drives several GPUs of the node, shards the pixel tiles
+ * across them itself and reduces with RCCL (ncclReduce over xGMI) inside ptmi_read_framebuffer: what a single-process host
+ * such as the Node program needs; (b) one process per GPU (ptmi_create + ptmi_set_shard) with the reduce done by the host
+ * program's own collective (bench.py: torch.distributed).
  * Every call returns PTMI_OK (0) or a negative ptmi_status; ptmi_last_error() gives the message.
  */
 #ifndef PTMI_H
@@ -22,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PTMI_API_VERSION 1
+#define PTMI_API_VERSION 2
 
 typedef struct ptmi_ctx ptmi_ctx;
 
@@ -85,6 +88,12 @@ typedef struct ptmi_stats {
   double other_ms;       /* k_generate + k_accumulate                                         */
   double prims_ms;       /* sum over k_prims launches (spheres, quads, root box)              */
   double bvh_ms;         /* sum over k_bvh launches (traversal)                               */
+  double generate_ms;    /* sum over k_generate launches (part of other_ms)                   */
+  double accumulate_ms;  /* sum over k_accumulate launches (part of other_ms)                 */
+  uint64_t generate_launches;
+  uint64_t accumulate_launches;
+  uint64_t devices;      /* GPUs behind this context (ptmi_create_multi); counters are summed over them, times are
+                          * the maximum over them                                            */
 } ptmi_stats;
 
 /* One hitScene result, the fields of the reference's HitRecord (shaders/header.wgsl:119-125). */
@@ -105,6 +114,14 @@ const char* ptmi_last_error(const ptmi_ctx* ctx);
 
 /* replaces WebGPU.init() (webgpu-utils.js:178-211): binds device `device_id`, creates one stream */
 int ptmi_create(ptmi_ctx** out, int device_id);
+/* The same for n_devices GPUs of this node behind ONE context: every call below is applied to all of them
+ * (uploads are replicated, renders run concurrently, one stream per GPU); the pixel tiles of this context's shard are
+ * dealt round-robin to the devices, and ptmi_read_framebuffer / ptmi_resolve_rgba8 first sum the per-device accumulation
+ * buffers into a gather buffer on device_ids[0] — one ncclReduce (f32 sum, W*H*4 values) over xGMI through librccl, loaded
+ * on first use — so the caller sees one image, bit-identical to the single-GPU one.  The reference's caller
+ * (renderer.js:91-124,184-191) needs no change.  A device id may be listed more than once (its shards then share that
+ * GPU and are summed by a kernel instead: how the multi-device path is tested on a one-GPU box). */
+int ptmi_create_multi(ptmi_ctx** out, const int* device_ids, int n_devices);
 void ptmi_destroy(ptmi_ctx* ctx);
 
 void ptmi_default_params(ptmi_params* p);
@@ -121,7 +138,9 @@ int ptmi_resize(ptmi_ctx* ctx, int width, int height);
 int ptmi_clear_framebuffer(ptmi_ctx* ctx);
 
 /* Pixel-tile sharding for multi-GPU: this context renders only pixels p with
- * (p / tile_pixels) % world == rank; other pixels of its framebuffer stay untouched (zero). */
+ * (p / tile_pixels) % world == rank; other pixels of its framebuffer stay untouched (zero).
+ * On a multi-device context the n local devices subdivide this shard: device i renders the tiles of
+ * rank * n + i out of world * n. */
 int ptmi_set_shard(ptmi_ctx* ctx, int rank, int world, int tile_pixels);
 
 /* replaces queue.writeBuffer(uniforms) + computePass(...) of one animation frame
@@ -136,6 +155,10 @@ int ptmi_render_frame(ptmi_ctx* ctx, const float* uniforms20);
 int ptmi_render(ptmi_ctx* ctx, const float* view16, uint32_t first_frame, uint32_t n_frames);
 
 int ptmi_synchronize(ptmi_ctx* ctx);
+
+/* Validates the uploaded buffers and builds the device-side digests now instead of inside the first render call
+ * (the analogue of createBindGroup, webgpu-utils.js:100-123).  Synchronous, so that a caller can time scene set-up. */
+int ptmi_prepare(ptmi_ctx* ctx);
 
 /* Framebuffer access (the reference never reads back; COPY_SRC exists, webgpu-utils.js:47).
  * read/write synchronise the stream; bytes must be W*H*16. */
@@ -153,8 +176,8 @@ int ptmi_stream(ptmi_ctx* ctx, void** stream);
 int ptmi_resolve_rgba8(ptmi_ctx* ctx, float frame_num, uint8_t* dst, size_t bytes);
 
 int ptmi_set_counters(ptmi_ctx* ctx, int enabled);
-/* 0 = off; 1 = HIP events around every kernel launch; 2 = only around k_bvh (the dominant kernel): fewer stream
- * markers, for timing a region whose wall clock also matters. */
+/* 0 = off; 1 = HIP events around every kernel launch; 2 / 3 / 4 / 5 = only around k_bvh / k_shade / k_generate /
+ * k_accumulate: fewer stream markers, for timing ONE kernel inside a region whose wall clock also matters. */
 int ptmi_set_timing(ptmi_ctx* ctx, int enabled);
 int ptmi_get_stats(ptmi_ctx* ctx, ptmi_stats* out); /* synchronises */
 int ptmi_reset_stats(ptmi_ctx* ctx);

@@ -33,8 +33,8 @@ def test_addon_loads_and_exports_surface(pkg):
     assert os.path.exists(os.path.join(JS, "ptmi.node")), "run __graft_entry__.build()"
     out = _run([node, "-e", "const p=require('./ptmi.node');console.log(JSON.stringify({v:p.version(),k:Object.keys(p).sort(),buf:p.BUF,d:p.defaultParams()}))"], cwd=JS)
     o = json.loads(out)
-    assert o["v"] == 1
-    assert set(o["k"]) >= {"create", "destroy", "upload", "resize", "renderFrame", "render", "readFramebuffer", "stats", "buildBVH", "buildBVHSAH", "buildBVHDevice", "parseObj", "setParams", "resolveRGBA8"}
+    assert o["v"] == 2
+    assert set(o["k"]) >= {"create", "prepare", "destroy", "upload", "resize", "renderFrame", "render", "readFramebuffer", "stats", "buildBVH", "buildBVHSAH", "buildBVHDevice", "parseObj", "setParams", "resolveRGBA8"}
     assert o["buf"] == pkg.ptmi.BUF
     assert o["d"]["max_bounces"] == 100 and o["d"]["stack_size"] == 20 and o["d"]["background"] == [0, 1, 1]
 
@@ -100,3 +100,20 @@ def test_node_host_renders_bit_exact(tmp_path, pkg, oracle):
     got = np.fromfile(raw, np.float32).reshape(96, 160, 4)
     want, _ = oracle.render(b, 160, 96, cornell_view(pkg, "oblique"), 1, 13, max_bounces=7)
     assert_same_bits(got, want, "node host, render-ahead")
+
+
+@pytest.mark.gpu
+@needs_node
+def test_node_host_multi_device_context(tmp_path, pkg, oracle):
+    """create([0, 0, 0]): ONE context, three shards (here on one GPU), tiles dealt round-robin, summed on read-back — the image
+    and the exact ray count are those of the single-device run.  The reference-shaped Renderer above it is unchanged."""
+    raw = tmp_path / "fb.f32"
+    b = pkg.scenes.golden_buffers("c2m")
+    args = [node, "app.mjs", "--golden", os.path.join(ROOT, "tests", "golden", "c2m"), "--width", "160", "--height", "96", "--bounces", "7", "--camera", "oblique", "--raw", str(raw),
+            "--devices", "0,0,0", "--frames", "5"]
+    out = _run(args, cwd=JS, env=dict(os.environ, PTMI_RENDER_AHEAD="0"))
+    st = json.loads(out)["stats"]
+    got = np.fromfile(raw, np.float32).reshape(96, 160, 4)
+    want, ost = oracle.render(b, 160, 96, cornell_view(pkg, "oblique"), 1, 5, max_bounces=7)
+    assert_same_bits(got, want, "node host, 3 shards in one context")
+    assert st["rays"] == ost["rays"] and st["devices"] == 3

@@ -1,0 +1,97 @@
+"""ptmi_create_multi: one context over several GPUs — tiles of the caller's shard dealt round-robin to the local devices, ONE
+reduce of the accumulation buffers inside ptmi_read_framebuffer (ncclReduce over xGMI when every shard has its own GPU).
+A one-GPU box can list device 0 several times: the shards then share the GPU and are summed by a kernel; the RCCL library
+itself is exercised with a one-rank communicator (PTMI_MULTI_REDUCE=rccl)."""
+import numpy as np
+import pytest
+
+from conftest import assert_same_bits, cornell_view
+
+pytestmark = pytest.mark.gpu
+
+
+def _render(pkg, devices, b, view, w, h, frames, **params):
+    with pkg.Context(devices) as ctx:
+        ctx.upload_scene(b)
+        ctx.set_params(**params)
+        ctx.resize(w, h)
+        ctx.set_counters(True)
+        ctx.render(view, 1, frames)
+        fb = ctx.read_framebuffer()
+        st = ctx.stats()
+        px = ctx.resolve_rgba8(frames)
+    return fb, st, px
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_shards_in_one_context_equal_single_device(pkg, oracle, n):
+    b = pkg.scenes.golden_buffers("default")  # spheres, fog volumes, quads, a cube mesh
+    view = cornell_view(pkg, "default") if "default" in pkg.scenes.CAMERAS else cornell_view(pkg)
+    one, st1, px1 = _render(pkg, 0, b, view, 200, 120, 6, max_bounces=6)
+    many, stn, pxn = _render(pkg, [0] * n, b, view, 200, 120, 6, max_bounces=6)
+    assert_same_bits(many, one, "%d shards in one context" % n)
+    assert np.array_equal(px1, pxn)
+    for k in ("rays", "paths", "node_visits", "tri_tests", "sphere_tests", "quad_tests", "mat_fetches"):
+        assert stn[k] == st1[k], k
+    assert stn["devices"] == n and st1["devices"] == 1
+    want, ost = oracle.render(b, 200, 120, view, 1, 6, max_bounces=6)
+    assert_same_bits(many, want, "vs oracle")
+    assert stn["rays"] == ost["rays"]
+
+
+def test_multi_context_progressive_frames_checkpoint_and_nested_shard(pkg, oracle):
+    """render_frame (incl. resetBuffer), reading back in the middle (the per-device buffers must stay partial sums),
+    write_framebuffer (scattered to the owners) and a caller-side shard on top of the local one."""
+    b = pkg.scenes.golden_buffers("c2m")
+    view, v2 = cornell_view(pkg), cornell_view(pkg, "oblique")
+    W, H = 96, 64
+
+    def u(frame, reset, v):
+        return np.concatenate([np.array([W, H, frame, reset], np.float32), np.asarray(v, np.float32).reshape(-1)])
+
+    with pkg.Context([0, 0]) as ctx:
+        ctx.upload_scene(b)
+        ctx.set_params(max_bounces=5)
+        ctx.resize(W, H)
+        for f in range(1, 4):
+            ctx.render_frame(u(f, 0, view))
+        mid = ctx.read_framebuffer()
+        want, _ = oracle.render(b, W, H, view, 1, 3, max_bounces=5)
+        assert_same_bits(mid, want, "after 3 frames")
+        for f in range(4, 6):
+            ctx.render_frame(u(f, 0, view))
+        want5, _ = oracle.render(b, W, H, view, 1, 5, max_bounces=5)
+        assert_same_bits(ctx.read_framebuffer(), want5, "after 5 frames, read twice")
+        ctx.render_frame(u(1, 1, v2))  # camera moved: resetBuffer = 1 replaces every pixel
+        want_r, _ = oracle.render(b, W, H, v2, 1, 1, max_bounces=5)
+        assert_same_bits(ctx.read_framebuffer(), want_r, "after reset")
+        ctx.write_framebuffer(want5)  # resume from a checkpoint
+        ctx.render(view, 6, 2)
+        want7, _ = oracle.render(b, W, H, view, 1, 7, max_bounces=5)
+        assert_same_bits(ctx.read_framebuffer(), want7, "checkpoint + 2 frames")
+        # caller-side shard (2 processes) on top of the 2 local devices: this context owns ranks 2 and 3 of 4
+        ctx.clear()
+        ctx.set_shard(1, 2, 64)
+        ctx.render(view, 1, 2)
+        part = ctx.read_framebuffer().reshape(-1, 4)
+        full, _ = oracle.render(b, W, H, view, 1, 2, max_bounces=5)
+        tile = np.arange(W * H) // 64
+        mine = (tile % 4) >= 2
+        assert_same_bits(part[mine], full.reshape(-1, 4)[mine], "owned tiles")
+        assert not part[~mine].any()
+        with pytest.raises(pkg.PtmiError):
+            ctx.framebuffer_device_ptr()
+
+
+def test_rccl_library_one_rank_communicator(pkg, oracle, monkeypatch):
+    """PTMI_MULTI_REDUCE=rccl on a single device: librccl is loaded, ncclCommInitAll builds a one-rank communicator and
+    ptmi_read_framebuffer goes through ncclReduce (a copy for one rank).  What a one-GPU box can check of the RCCL path."""
+    monkeypatch.setenv("PTMI_MULTI_REDUCE", "rccl")
+    b = pkg.scenes.golden_buffers("c1")
+    view = cornell_view(pkg)
+    fb, st, _ = _render(pkg, [0], b, view, 128, 128, 3, max_bounces=4)
+    want, ost = oracle.render(b, 128, 128, view, 1, 3, max_bounces=4)
+    assert_same_bits(fb, want, "through ncclReduce")
+    assert st["rays"] == ost["rays"]
+    with pytest.raises(pkg.PtmiError):  # a communicator cannot hold one GPU twice
+        pkg.Context([0, 0])

@@ -142,6 +142,20 @@ def test_upload_validation_errors(ctx, pkg):
     ctx.upload_scene({**b, "quads": q})
     with pytest.raises(pkg.PtmiError):
         ctx.render(cornell_view(pkg), 1, 1)
+    # hostile leaf fields: a count near 2^31 whose sum with the first index would wrap, NaN / huge counts, axis and type fields
+    nodes = b["bvh"].reshape(-1, 12)
+    leaf = int(np.nonzero(nodes[:, 7] == 2.0)[0][-1])
+    inner = int(np.nonzero(nodes[:, 7] != 2.0)[0][0])
+    for row, col, val in ((leaf, 9, 2147483520.0), (leaf, 9, np.nan), (leaf, 9, 3.0e38), (leaf, 9, -1.0), (leaf, 8, np.nan), (leaf, 8, 4.0e9),
+                          (inner, 11, np.nan), (inner, 11, 3.0), (inner, 11, -1.0), (inner, 7, np.nan), (inner, 7, 3.0e38), (inner, 3, np.nan)):
+        h = nodes.copy()
+        if col == 9 and val == 2147483520.0:
+            h[leaf, 8] = 200.0  # first > 127: first + count overflows an int
+        h[row, col] = val
+        ctx.upload_scene({**b, "bvh": h.reshape(-1)})
+        with pytest.raises(pkg.PtmiError) as e:
+            ctx.render(cornell_view(pkg), 1, 1)
+        assert e.value.status == -5, (row, col, val)
     ctx.upload_scene(b)
     ctx.render(cornell_view(pkg), 1, 1)  # recovers
     ctx.synchronize()
@@ -497,7 +511,8 @@ def test_render_frame_render_ahead_is_invisible(ctx, pkg, oracle, monkeypatch):
 
 def test_auto_batch_shrinks_when_memory_is_short(pkg, oracle, monkeypatch):
     """With the automatic frames-in-flight budget, an allocation failure halves the batch instead of failing the render
-    (PTMI_TEST_ALLOC_LIMIT makes every device allocation above 256 MB fail: 512 frames of 256x256 need 600 MB per state array,
+    (PTMI_TEST_ALLOC_LIMIT turns every device allocation above 256 MB into a hipMalloc that really fails — 2^60 bytes —, so the HIP
+    runtime's error state is what a real out-of-memory leaves behind: 512 frames of 256x256 need 600 MB per state array,
     so the batch shrinks 512 -> 256 -> 128).  Same image as always; an explicit frames_in_flight still fails loudly."""
     monkeypatch.setenv("PTMI_TEST_ALLOC_LIMIT", str(256 << 20))
     b = pkg.scenes.golden_buffers("c1")

@@ -1,6 +1,8 @@
 // ptmi.hip — libptmi.so: context management, scene upload/validation/digests, wavefront scheduling and
 // the C ABI of include/ptmi.h.  gfx950 (MI355X) only; build: see webgpu-path-tracer_amd/_build.py.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: librccl is loaded on first multi-device use (see Rccl below)
 
 #include <algorithm>
 #include <cmath>
@@ -8,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ptmi.h"
@@ -28,10 +31,15 @@ struct DBuf {
     p = nullptr;
     cap = 0;
     if (bytes == 0) return hipSuccess;
-    if (const char* lim = getenv("PTMI_TEST_ALLOC_LIMIT"))  // tests: pretend the board is smaller
-      if (bytes > strtoull(lim, nullptr, 10)) return hipErrorOutOfMemory;
-    hipError_t e = hipMalloc(&p, bytes);
+    size_t ask = bytes;
+    if (const char* lim = getenv("PTMI_TEST_ALLOC_LIMIT"))  // tests: pretend the board is smaller — through a hipMalloc that really fails
+      if (bytes > strtoull(lim, nullptr, 10)) ask = (size_t)1 << 60;
+    hipError_t e = hipMalloc(&p, ask);
     if (e == hipSuccess) cap = bytes;
+    else {
+      p = nullptr;
+      (void)hipGetLastError();  // the failure is reported through the return value; do not leave it behind as the runtime's "last error"
+    }
     return e;
   }
   void release() {
@@ -45,7 +53,7 @@ struct DBuf {
   }
 };
 
-enum TimerTag { T_PRIMS = 0, T_SHADE = 1, T_OTHER = 2, T_RENDER = 3, T_BVH = 4 };
+enum TimerTag { T_PRIMS = 0, T_SHADE = 1, T_GENERATE = 2, T_RENDER = 3, T_BVH = 4, T_ACCUM = 5 };
 
 }  // namespace
 
@@ -97,6 +105,16 @@ struct ptmi_ctx {
   int static_streak = 0;  // consecutive ptmi_render_frame calls with the same view, frame numbers +1, no reset
   int ahead_batch = 8;
 
+  // Multi-device context (ptmi_create_multi): this object is local device 0, `peers` are the contexts of local devices
+  // 1..n-1 (plain single-device contexts).  The caller's shard (ptmi_set_shard) is subdivided among the n of them.
+  bool multi = false;
+  std::vector<ptmi_ctx*> peers;
+  int proc_rank = 0, proc_world = 1, proc_tile = 4096;
+  bool use_rccl = false;
+  std::vector<ncclComm_t> comms;  // one per local device, same order as {this, peers...}
+  DBuf d_fb_gather, d_fb_stage;   // on this device: the sum of all local accumulation buffers / a peer's buffer in transit
+
+  bool batch_enqueued = false;  // render_batch: has anything been put on the stream yet? (a failure before that point may be retried)
   bool counters = false;
   int timing = 0;  // 0 off, 1 every kernel, 2 only k_bvh (the dominant kernel) — see ptmi_set_timing
   ptmi_stats stats{};
@@ -137,7 +155,10 @@ struct ScopedSpan {  // records a begin/end event pair around launches when timi
   ptmi_ctx* c;
   ptmi_ctx::Span s{};
   bool on;
-  ScopedSpan(ptmi_ctx* c_, int tag) : c(c_), on(c_->timing == 1 || (c_->timing == 2 && tag == T_BVH)) {
+  static bool wanted(int timing, int tag) {  // ptmi_set_timing: 1 = everything, 2..5 = one kernel only
+    return timing == 1 || (timing == 2 && tag == T_BVH) || (timing == 3 && tag == T_SHADE) || (timing == 4 && tag == T_GENERATE) || (timing == 5 && tag == T_ACCUM);
+  }
+  ScopedSpan(ptmi_ctx* c_, int tag) : c(c_), on(wanted(c_->timing, tag)) {
     if (!on) return;
     s.tag = tag;
     s.a = get_event(c);
@@ -157,7 +178,8 @@ void drain_spans(ptmi_ctx* c) {  // call after the stream is idle
       if (s.tag == T_PRIMS) c->stats.prims_ms += ms, c->stats.intersect_ms += ms;
       else if (s.tag == T_BVH) c->stats.bvh_ms += ms, c->stats.intersect_ms += ms;
       else if (s.tag == T_SHADE) c->stats.shade_ms += ms;
-      else if (s.tag == T_OTHER) c->stats.other_ms += ms;
+      else if (s.tag == T_GENERATE) c->stats.generate_ms += ms, c->stats.other_ms += ms;
+      else if (s.tag == T_ACCUM) c->stats.accumulate_ms += ms, c->stats.other_ms += ms;
       else c->stats.render_ms += ms;
     }
     c->ev_pool.push_back(s.a);
@@ -285,17 +307,21 @@ int prepare_scene(ptmi_ctx* c) {
         return fail(c, PTMI_ERR_BAD_SCENE, msg);
       }
       const float* nd = &c->h_bvh[12 * (size_t)i];
-      if ((int)nd[7] == 2) {  // leaf (hitRay.wgsl:45,56)
-        int first, cnt = (int)nd[9];
-        if (!(nd[9] >= 0.0f) || cnt < 0 || (cnt > 0 && (!id_from_float(nd[8], n_tri, &first) || first + cnt > n_tri))) {
+      if (nd[7] >= 2.0f && nd[7] < 3.0f) {  // leaf: i32(prim_type) == 2 (hitRay.wgsl:45,56)
+        int first = 0, cnt = 0;
+        // count in [0, n_tri] and first + count <= n_tri, compared without an addition that could wrap
+        const bool cnt_ok = nd[9] >= 0.0f && nd[9] <= (float)n_tri && (cnt = (int)nd[9]) <= n_tri;
+        if (!cnt_ok || (cnt > 0 && (!id_from_float(nd[8], n_tri, &first) || cnt > n_tri - first))) {
           snprintf(msg, sizeof msg, "bvh: leaf %d references triangles outside [0,%d)", i, n_tri);
           return fail(c, PTMI_ERR_BAD_SCENE, msg);
         }
         seen[i] = 2;
         c->bvh_depth = std::max(c->bvh_depth, depth);
       } else {
-        int right, axis = (int)nd[11];
-        if (!id_from_float(nd[3], n_node, &right) || right <= i + 1 || i + 1 >= n_node || !(nd[11] >= 0.0f) || axis > 2) {
+        int right = 0;
+        const bool type_ok = nd[7] > -2147483000.0f && nd[7] < 2147483000.0f;  // i32(prim_type) is defined (and != 2)
+        const bool axis_ok = nd[11] >= 0.0f && nd[11] < 3.0f;  // i32(axis) in {0, 1, 2}
+        if (!type_ok || !axis_ok || !id_from_float(nd[3], n_node, &right) || right <= i + 1 || i + 1 >= n_node) {
           snprintf(msg, sizeof msg, "bvh: inner node %d has right_offset/axis out of range", i);
           return fail(c, PTMI_ERR_BAD_SCENE, msg);
         }
@@ -309,7 +335,7 @@ int prepare_scene(ptmi_ctx* c) {
     int32_t r = 0;
     for (int i = 0; i < n_node; i++)
       if (seen[i] == 1) rank[i] = r++;
-    auto ref_of = [&](int j) -> uint32_t {
+    auto ref_of = [&](int j) -> uint32_t {  // (every node passed the range checks of the walk above)
       const float* nd = &c->h_bvh[12 * (size_t)j];
       if (seen[j] == 1) return (uint32_t)rank[j];
       int cnt = (int)nd[9];
@@ -501,6 +527,7 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
     else PTMI_LAUNCH_BVH(false, false);
   }
 #undef PTMI_LAUNCH_BVH
+  HIP_TRY(c, hipGetLastError());
   return PTMI_OK;
 }
 
@@ -541,13 +568,14 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
 
   const int n_steps = rc.num_samples * p.max_bounces;
   const size_t npaths = (size_t)rc.n_local * (size_t)n_frames;
+  c->batch_enqueued = false;
   int rcode = ensure_paths(c, npaths, n_steps + 2, rc.num_samples > 1);
-  if (rcode) return rcode;
+  if (rcode) return rcode;  // nothing is on the stream yet: ptmi_render may retry with a smaller batch
   StepCtl* ctl = c->d_ctl.as<StepCtl>();
   const uint32_t total = rc.n_local * (uint32_t)n_frames;
   const uint32_t bound = total + total / 8 + (uint32_t)c->num_cus * 8 * 1024;  // slots a step's queue can span
   const uint32_t ew_grid = std::max<uint32_t>(1, std::min<uint32_t>((total + kBlock - 1) / kBlock, (uint32_t)c->num_cus * 16));
-  const uint32_t sgrid = std::max<uint32_t>(1, std::min<uint32_t>((bound + kSChunk - 1) / kSChunk, (uint32_t)c->num_cus * (uint32_t)std::max(1, env_int("PTMI_SHADE_BLOCKS_PER_CU", 5))));
+  const uint32_t sgrid = std::max<uint32_t>(1, std::min<uint32_t>((bound + kSChunk - 1) / kSChunk, (uint32_t)c->num_cus * (uint32_t)std::min(8, std::max(1, env_int("PTMI_SHADE_BLOCKS_PER_CU", 5)))));  // <= 8: the queue buffers' slack is sized for that (ensure_paths)
   unsigned long long* tot = c->d_totals.as<unsigned long long>();
 
   // k_shade sorts its chunks by material class only when the scene has more than one (PTMI_SORT=0/1 overrides, for A/B runs)
@@ -555,11 +583,14 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   const bool sort = sort_env >= 0 ? sort_env != 0 : c->material_classes > 1;
 
   ScopedSpan whole(c, T_RENDER);
+  c->batch_enqueued = true;  // from here on a failure leaves a partly traced batch behind: never retried
+  HIP_TRY(c, hipMemsetAsync(ctl, 0, (size_t)(n_steps + 2) * sizeof(StepCtl), c->stream));
   {
-    ScopedSpan s(c, T_OTHER);
-    HIP_TRY(c, hipMemsetAsync(ctl, 0, (size_t)(n_steps + 2) * sizeof(StepCtl), c->stream));
+    ScopedSpan s(c, T_GENERATE);
     if (c->counters) hipLaunchKernelGGL(k_generate<true>, dim3(ew_grid), dim3(kBlock), 0, c->stream, c->S, rc, paths_of(c, 0, rc.num_samples > 1), ctl, c->d_heads.as<uint32_t>(), tot);
     else hipLaunchKernelGGL(k_generate<false>, dim3(ew_grid), dim3(kBlock), 0, c->stream, c->S, rc, paths_of(c, 0, rc.num_samples > 1), ctl, c->d_heads.as<uint32_t>(), tot);
+    HIP_TRY(c, hipGetLastError());
+    c->stats.generate_launches++;
   }
   for (int s = 0; s < n_steps; s++) {
     // With the reference's MAX_BOUNCES = 100 nearly all steps run on an empty queue (Russian roulette ends paths after
@@ -592,19 +623,31 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
       }
 #undef PTMI_LAUNCH_SHADE2
 #undef PTMI_LAUNCH_SHADE
+      HIP_TRY(c, hipGetLastError());  // launch errors surface per step, before k_accumulate touches the framebuffer
     }
     c->stats.intersect_launches++;
     c->stats.shade_launches++;
   }
   {
-    ScopedSpan s(c, T_OTHER);
+    ScopedSpan s(c, T_ACCUM);
     hipLaunchKernelGGL(k_accumulate, dim3(ew_grid), dim3(kBlock), 0, c->stream, rc, paths_of(c, 0, false), c->fb, ctl, n_steps, tot, 0,
                        fold < 0 ? n_frames : std::min(fold, n_frames));
+    c->stats.accumulate_launches++;
   }
   HIP_TRY(c, hipGetLastError());
   c->stats.frames += (uint64_t)n_frames;
   c->ahead.rc = rc;
   c->ahead.grid = ew_grid;
+  return PTMI_OK;
+}
+
+// totals[15]: a k_shade block found the next queue full and dropped paths (cannot happen with ensure_paths' sizing).  Every
+// synchronising call reports it, so that a damaged image is never handed out as a good one.  Call with the stream idle.
+int check_queue_overflow(ptmi_ctx* c) {
+  if (!c->d_totals.p) return PTMI_OK;
+  unsigned long long flag = 0;
+  HIP_TRY(c, hipMemcpy(&flag, c->d_totals.as<unsigned long long>() + 15, sizeof flag, hipMemcpyDeviceToHost));
+  if (flag) return fail(c, PTMI_ERR_STATE, "internal: a step's queue outgrew its buffer (paths were dropped); the framebuffer is incomplete");
   return PTMI_OK;
 }
 
@@ -614,6 +657,151 @@ int check_renderable(ptmi_ctx* c) {
   if (p.importance_sampling && c->has_unknown_material)
     return fail(c, PTMI_ERR_UNSUPPORTED,
                 "importance_sampling with a material_type outside {0,1,2,3}: the shader would read stale private state (scatterRec)");
+  return PTMI_OK;
+}
+
+// ---- multi-device contexts ---------------------------------------------------------------------------------------
+// librccl (RCCL = the NCCL API on ROCm; collectives run over xGMI between the GPUs of a node) is loaded when the first
+// multi-device context is created, so that single-GPU users of libptmi.so do not need it.
+struct Rccl {
+  void* lib = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclReduce) Reduce = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string why;
+  bool load() {
+    if (lib) return true;
+    const char* names[] = {getenv("PTMI_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      if (!n || !*n) continue;
+      lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+      why = dlerror();
+    }
+    if (!lib) return false;
+#define PTMI_RCCL_SYM(field, sym)                                  \
+  field = reinterpret_cast<decltype(field)>(dlsym(lib, #sym));     \
+  if (!field) {                                                    \
+    why = std::string("librccl lacks ") + #sym;                    \
+    dlclose(lib);                                                  \
+    lib = nullptr;                                                 \
+    return false;                                                  \
+  }
+    PTMI_RCCL_SYM(CommInitAll, ncclCommInitAll)
+    PTMI_RCCL_SYM(CommDestroy, ncclCommDestroy)
+    PTMI_RCCL_SYM(Reduce, ncclReduce)
+    PTMI_RCCL_SYM(GroupStart, ncclGroupStart)
+    PTMI_RCCL_SYM(GroupEnd, ncclGroupEnd)
+    PTMI_RCCL_SYM(GetErrorString, ncclGetErrorString)
+#undef PTMI_RCCL_SYM
+    return true;
+  }
+};
+Rccl g_rccl;
+
+#define RCCL_TRY(c, expr)                                                                                            \
+  do {                                                                                                               \
+    ncclResult_t _r = (expr);                                                                                        \
+    if (_r != ncclSuccess) return fail((c), PTMI_ERR_DEVICE, std::string(#expr) + ": " + g_rccl.GetErrorString(_r)); \
+  } while (0)
+
+// fn(ctx) on the context itself and on every peer; `parallel` = one host thread per device, so that calls which block
+// (allocation, the occasional queue-length readback of a long render) do not serialise the GPUs.
+template <class F>
+int on_all_devices(ptmi_ctx* c, F fn, bool parallel = false) {
+  const size_t n = c->peers.size();
+  if (n == 0) return fn(c);
+  std::vector<int> rcs(n + 1, PTMI_OK);
+  if (parallel) {
+    std::vector<std::thread> th;
+    th.reserve(n);
+    for (size_t i = 0; i < n; i++) th.emplace_back([&rcs, &fn, c, i] { rcs[i + 1] = fn(c->peers[i]); });
+    rcs[0] = fn(c);
+    for (auto& t : th) t.join();
+  } else {
+    rcs[0] = fn(c);
+    for (size_t i = 0; i < n && !rcs[0]; i++) rcs[i + 1] = fn(c->peers[i]);
+  }
+  for (size_t i = 1; i <= n; i++)
+    if (rcs[i] && !rcs[0]) {
+      c->err = "local device #" + std::to_string(i) + " (GPU " + std::to_string(c->peers[i - 1]->device) + "): " + c->peers[i - 1]->err;
+      return rcs[i];
+    }
+  return rcs[0];
+}
+
+__global__ __launch_bounds__(kBlock) void k_add_into(float4* __restrict__ dst, const float4* __restrict__ src, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const float4 a = dst[i], b = src[i];
+    dst[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+}
+
+// The one collective of a multi-device render: sum the per-device accumulation buffers into d_fb_gather on local device 0.
+// Every pixel is non-zero in exactly one of them (x + 0 = x), so the sum is the single-GPU image bit for bit whatever
+// the order.  The per-device buffers are left as they are, so rendering can go on afterwards.
+int gather_framebuffer(ptmi_ctx* c, float4** out) {
+  if (!c->multi) {
+    *out = c->fb;
+    return PTMI_OK;
+  }
+  const size_t bytes = c->fb_bytes, n4 = bytes / 16;
+  int r = on_all_devices(c, [](ptmi_ctx* q) -> int {
+    HIP_TRY(q, hipSetDevice(q->device));
+    HIP_TRY(q, hipStreamSynchronize(q->stream));
+    return PTMI_OK;
+  });
+  if (r) return r;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, c->d_fb_gather.ensure(bytes));
+  float4* g = c->d_fb_gather.as<float4>();
+  if (c->use_rccl) {
+    // ncclReduce(sendbuff = this device's buffer, recvbuff = the gather buffer on the root, W*H*4 floats, sum, root 0)
+    RCCL_TRY(c, g_rccl.GroupStart());
+    for (size_t i = 0; i <= c->peers.size(); i++) {
+      ptmi_ctx* q = i ? c->peers[i - 1] : c;
+      HIP_TRY(c, hipSetDevice(q->device));
+      RCCL_TRY(c, g_rccl.Reduce(q->fb, i ? (void*)q->fb : (void*)g, n4 * 4, ncclFloat, ncclSum, 0, c->comms[i], q->stream));
+    }
+    RCCL_TRY(c, g_rccl.GroupEnd());
+    for (size_t i = 0; i <= c->peers.size(); i++) {
+      ptmi_ctx* q = i ? c->peers[i - 1] : c;
+      HIP_TRY(c, hipSetDevice(q->device));
+      HIP_TRY(c, hipStreamSynchronize(q->stream));
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+  } else {
+    // shards that share this GPU (tests on a one-GPU box), or PTMI_MULTI_REDUCE=copy: peer copy + add kernel
+    HIP_TRY(c, hipMemcpyAsync(g, c->fb, bytes, hipMemcpyDeviceToDevice, c->stream));
+    const unsigned grid = (unsigned)std::min<size_t>((n4 + kBlock - 1) / kBlock, (size_t)c->num_cus * 8);
+    for (ptmi_ctx* q : c->peers) {
+      const float4* src = q->fb;
+      if (q->device != c->device) {
+        HIP_TRY(c, c->d_fb_stage.ensure(bytes));
+        HIP_TRY(c, hipMemcpyPeerAsync(c->d_fb_stage.p, c->device, q->fb, q->device, bytes, c->stream));
+        src = c->d_fb_stage.as<float4>();
+      }
+      hipLaunchKernelGGL(k_add_into, dim3(grid), dim3(kBlock), 0, c->stream, g, src, n4);
+      HIP_TRY(c, hipGetLastError());
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  *out = g;
+  return PTMI_OK;
+}
+
+int apply_shard(ptmi_ctx* c) {  // deal the caller's shard to the local devices
+  const int n = (int)c->peers.size() + 1;
+  for (int i = 0; i < n; i++) {
+    ptmi_ctx* q = i ? c->peers[i - 1] : c;
+    q->rank = c->proc_rank * n + i;
+    q->world = c->proc_world * n;
+    q->tile = c->proc_tile;
+    q->ahead.valid = false;
+  }
   return PTMI_OK;
 }
 
@@ -690,8 +878,68 @@ int ptmi_create(ptmi_ctx** out, int device_id) {
   return PTMI_OK;
 }
 
+int ptmi_create_multi(ptmi_ctx** out, const int* device_ids, int n_devices) {
+  if (!out) return fail(nullptr, PTMI_ERR_INVALID_ARG, "ptmi_create_multi: out is null");
+  *out = nullptr;
+  if (!device_ids || n_devices < 1 || n_devices > 64) return fail(nullptr, PTMI_ERR_INVALID_ARG, "ptmi_create_multi: need 1 <= n_devices <= 64 device ids");
+  ptmi_ctx* c = nullptr;
+  int r = ptmi_create(&c, device_ids[0]);
+  if (r) return r;
+  c->multi = true;
+  bool distinct = true;
+  for (int i = 1; i < n_devices; i++) {
+    ptmi_ctx* q = nullptr;
+    r = ptmi_create(&q, device_ids[i]);
+    if (r) {
+      ptmi_destroy(c);
+      return r;  // (the message is in the thread's create-error slot)
+    }
+    c->peers.push_back(q);
+    for (int j = 0; j < i; j++) distinct = distinct && device_ids[j] != device_ids[i];
+  }
+  // The reduce: RCCL whenever every shard has a GPU of its own (a communicator cannot hold one GPU twice); shards that
+  // share a GPU are summed by a kernel.  PTMI_MULTI_REDUCE=copy forces the peer-copy path, =rccl forces RCCL even for a
+  // single device (a one-rank communicator: exercises the library on a one-GPU box).
+  const char* mode = getenv("PTMI_MULTI_REDUCE");
+  const bool force_rccl = mode && !strcmp(mode, "rccl"), force_copy = mode && !strcmp(mode, "copy");
+  c->use_rccl = !force_copy && distinct && (n_devices > 1 || force_rccl);
+  if (force_rccl && !distinct) {
+    ptmi_destroy(c);
+    return fail(nullptr, PTMI_ERR_UNSUPPORTED, "PTMI_MULTI_REDUCE=rccl needs distinct device ids (an RCCL communicator cannot hold a GPU twice)");
+  }
+  if (c->use_rccl) {
+    if (!g_rccl.load()) {
+      ptmi_destroy(c);
+      return fail(nullptr, PTMI_ERR_DEVICE, "ptmi_create_multi: cannot load librccl (" + g_rccl.why + "); set PTMI_RCCL_LIB, or PTMI_MULTI_REDUCE=copy for peer copies instead");
+    }
+    c->comms.assign((size_t)n_devices, nullptr);
+    ncclResult_t nr = g_rccl.CommInitAll(c->comms.data(), n_devices, device_ids);
+    if (nr != ncclSuccess) {
+      c->comms.clear();
+      ptmi_destroy(c);
+      return fail(nullptr, PTMI_ERR_DEVICE, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(nr));
+    }
+  }
+  apply_shard(c);
+  *out = c;
+  return PTMI_OK;
+}
+
 void ptmi_destroy(ptmi_ctx* c) {
   if (!c) return;
+  for (ptmi_ctx* q : c->peers) {
+    if (q->stream) {
+      (void)hipSetDevice(q->device);
+      (void)hipStreamSynchronize(q->stream);
+    }
+  }
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (ncclComm_t cm : c->comms)
+    if (cm) (void)g_rccl.CommDestroy(cm);
+  c->comms.clear();
+  for (ptmi_ctx* q : c->peers) ptmi_destroy(q);
+  c->peers.clear();
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   drain_spans(c);
@@ -699,7 +947,7 @@ void ptmi_destroy(ptmi_ctx* c) {
   for (DBuf* b : {&c->d_quad_unit_n, &c->d_spheres, &c->d_sphere_info, &c->d_quads, &c->d_quad_mat, &c->d_tris, &c->d_pretri, &c->d_meshes, &c->d_xforms,
                   &c->d_mats, &c->d_pairs, &c->d_leaf_table, &c->d_fb_own, &c->d_q0[0], &c->d_q0[1], &c->d_q1[0], &c->d_q1[1], &c->d_q2[0],
                   &c->d_q2[1], &c->d_tp[0], &c->d_tp[1], &c->d_hm[0], &c->d_hm[1], &c->d_uv, &c->d_acc, &c->d_pixsum, &c->d_ctl, &c->d_totals,
-                  &c->d_scratch, &c->d_spill, &c->d_heads})
+                  &c->d_scratch, &c->d_spill, &c->d_heads, &c->d_fb_gather, &c->d_fb_stage})
     b->release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -714,6 +962,10 @@ int ptmi_set_params(ptmi_ctx* c, const ptmi_params* p) {
   if (!(p->fov_degrees > 0.0f && p->fov_degrees < 180.0f)) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_set_params: fov_degrees must be in (0,180)");
   c->prm = *p;
   c->ahead.valid = false;
+  for (ptmi_ctx* q : c->peers) {
+    q->prm = *p;
+    q->ahead.valid = false;
+  }
   return PTMI_OK;
 }
 
@@ -742,6 +994,10 @@ int ptmi_upload(ptmi_ctx* c, int which, const void* data, size_t bytes) {
   }
   c->scene_dirty = true;
   c->ahead.valid = false;
+  for (ptmi_ctx* q : c->peers) {  // the scene is replicated on every device
+    int r = ptmi_upload(q, which, data, bytes);
+    if (r) return fail(c, r, q->err);
+  }
   return PTMI_OK;
 }
 
@@ -758,6 +1014,10 @@ int ptmi_resize(ptmi_ctx* c, int width, int height) {
   c->W = width;
   c->H = height;
   HIP_TRY(c, hipMemsetAsync(c->fb, 0, bytes, c->stream));
+  for (ptmi_ctx* q : c->peers) {
+    int r = ptmi_resize(q, width, height);
+    if (r) return fail(c, r, q->err);
+  }
   return PTMI_OK;
 }
 
@@ -765,20 +1025,29 @@ int ptmi_clear_framebuffer(ptmi_ctx* c) {
   if (!c || !c->fb) return fail(c, PTMI_ERR_STATE, "ptmi_clear_framebuffer: no framebuffer");
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipMemsetAsync(c->fb, 0, c->fb_bytes, c->stream));
+  for (ptmi_ctx* q : c->peers) {
+    int r = ptmi_clear_framebuffer(q);
+    if (r) return fail(c, r, q->err);
+  }
   return PTMI_OK;
 }
 
 int ptmi_set_shard(ptmi_ctx* c, int rank, int world, int tile_pixels) {
   if (!c) return PTMI_ERR_INVALID_ARG;
   if (world < 1 || rank < 0 || rank >= world || tile_pixels < 1) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_set_shard: need 0 <= rank < world, tile_pixels >= 1");
+  if (c->multi) {
+    if ((int64_t)world * (int64_t)(c->peers.size() + 1) > (1 << 30)) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_set_shard: world too large");
+    c->proc_rank = rank, c->proc_world = world, c->proc_tile = tile_pixels;
+    return apply_shard(c);
+  }
   c->rank = rank, c->world = world, c->tile = tile_pixels;
   c->ahead.valid = false;
   return PTMI_OK;
 }
 
-int ptmi_render_frame(ptmi_ctx* c, const float* u) {
-  if (!c || !u) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_render_frame: null argument");
+static int render_frame_one(ptmi_ctx* c, const float* u) {
   HIP_TRY(c, hipSetDevice(c->device));
+  (void)hipGetLastError();  // a stale error of an earlier, already reported failure must not be blamed on this call
   int r = prepare_scene(c);
   if (r) return r;
   r = check_renderable(c);
@@ -826,9 +1095,14 @@ int ptmi_render_frame(ptmi_ctx* c, const float* u) {
   return PTMI_OK;
 }
 
-int ptmi_render(ptmi_ctx* c, const float* view16, uint32_t first_frame, uint32_t n_frames) {
-  if (!c || !view16) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_render: null argument");
+int ptmi_render_frame(ptmi_ctx* c, const float* u) {
+  if (!c || !u) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_render_frame: null argument");
+  return on_all_devices(c, [u](ptmi_ctx* q) { return render_frame_one(q, u); }, true);
+}
+
+static int render_one(ptmi_ctx* c, const float* view16, uint32_t first_frame, uint32_t n_frames) {
   HIP_TRY(c, hipSetDevice(c->device));
+  (void)hipGetLastError();  // a stale error of an earlier, already reported failure must not be blamed on this call
   int r = prepare_scene(c);
   if (r) return r;
   r = check_renderable(c);
@@ -846,8 +1120,10 @@ int ptmi_render(ptmi_ctx* c, const float* view16, uint32_t first_frame, uint32_t
   for (uint32_t done = 0; done < n_frames;) {
     uint32_t nb = std::min(F, n_frames - done);
     r = render_batch(c, view16, first_frame + done, (int)nb, 0);
-    if (r == PTMI_ERR_NO_MEMORY && nb > 1 && c->prm.frames_in_flight <= 0) {
-      F = std::max<uint32_t>(1, nb / 2);  // the automatic budget did not fit this board (or what is left of it): halve and retry
+    if (r == PTMI_ERR_NO_MEMORY && !c->batch_enqueued && nb > 1 && c->prm.frames_in_flight <= 0) {
+      // the automatic budget did not fit this board (or what is left of it) and the path buffers could not be allocated —
+      // nothing of this batch has been enqueued, so halving and rendering the same frames again cannot count them twice
+      F = std::max<uint32_t>(1, nb / 2);
       continue;
     }
     if (r) return r;
@@ -856,12 +1132,32 @@ int ptmi_render(ptmi_ctx* c, const float* view16, uint32_t first_frame, uint32_t
   return PTMI_OK;
 }
 
-int ptmi_synchronize(ptmi_ctx* c) {
-  if (!c) return PTMI_ERR_INVALID_ARG;
+int ptmi_render(ptmi_ctx* c, const float* view16, uint32_t first_frame, uint32_t n_frames) {
+  if (!c || !view16) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_render: null argument");
+  return on_all_devices(c, [=](ptmi_ctx* q) { return render_one(q, view16, first_frame, n_frames); }, true);
+}
+
+static int synchronize_one(ptmi_ctx* c) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_spans(c);
-  return PTMI_OK;
+  return check_queue_overflow(c);
+}
+
+int ptmi_synchronize(ptmi_ctx* c) {
+  if (!c) return PTMI_ERR_INVALID_ARG;
+  return on_all_devices(c, synchronize_one);
+}
+
+int ptmi_prepare(ptmi_ctx* c) {
+  if (!c) return PTMI_ERR_INVALID_ARG;
+  return on_all_devices(c, [](ptmi_ctx* q) -> int {
+    HIP_TRY(q, hipSetDevice(q->device));
+    int r = prepare_scene(q);
+    if (r) return r;
+    HIP_TRY(q, hipStreamSynchronize(q->stream));
+    return PTMI_OK;
+  }, true);
 }
 
 int ptmi_read_framebuffer(ptmi_ctx* c, float* dst, size_t bytes) {
@@ -869,16 +1165,41 @@ int ptmi_read_framebuffer(ptmi_ctx* c, float* dst, size_t bytes) {
   if (!c->fb) return fail(c, PTMI_ERR_STATE, "ptmi_read_framebuffer: no framebuffer");
   if (bytes != (size_t)c->W * c->H * 16) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_read_framebuffer: bytes != W*H*16");
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipMemcpyAsync(dst, c->fb, bytes, hipMemcpyDeviceToHost, c->stream));
+  float4* src = nullptr;
+  int r = gather_framebuffer(c, &src);  // multi-device: the one reduce of the render (RCCL over xGMI); else c->fb itself
+  if (r) return r;
+  HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_spans(c);
-  return PTMI_OK;
+  return on_all_devices(c, [](ptmi_ctx* q) -> int {
+    HIP_TRY(q, hipSetDevice(q->device));
+    drain_spans(q);
+    return check_queue_overflow(q);
+  });
 }
 
 int ptmi_write_framebuffer(ptmi_ctx* c, const float* src, size_t bytes) {
   if (!c || !src) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_write_framebuffer: null argument");
   if (!c->fb) return fail(c, PTMI_ERR_STATE, "ptmi_write_framebuffer: no framebuffer");
   if (bytes != (size_t)c->W * c->H * 16) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_write_framebuffer: bytes != W*H*16");
+  if (c->multi && !c->peers.empty()) {
+    // every device gets its own tiles of the image and zeros elsewhere, as if it had rendered them itself
+    const size_t npix = (size_t)c->W * c->H;
+    std::vector<float> part(npix * 4);
+    for (size_t i = 0; i <= c->peers.size(); i++) {
+      ptmi_ctx* q = i ? c->peers[i - 1] : c;
+      for (size_t px = 0; px < npix; px++) {
+        const bool mine = (px / (size_t)q->tile) % (size_t)q->world == (size_t)q->rank;
+        for (int k = 0; k < 4; k++) part[4 * px + k] = mine ? src[4 * px + k] : 0.0f;
+      }
+      HIP_TRY(c, hipSetDevice(q->device));
+      q->ahead.valid = false;
+      HIP_TRY(c, hipMemcpyAsync(q->fb, part.data(), bytes, hipMemcpyHostToDevice, q->stream));
+      HIP_TRY(c, hipStreamSynchronize(q->stream));
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    return PTMI_OK;
+  }
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipMemcpyAsync(c->fb, src, bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -888,6 +1209,7 @@ int ptmi_write_framebuffer(ptmi_ctx* c, const float* src, size_t bytes) {
 int ptmi_framebuffer_device_ptr(ptmi_ctx* c, void** p, size_t* bytes) {
   if (!c || !p) return PTMI_ERR_INVALID_ARG;
   if (!c->fb) return fail(c, PTMI_ERR_STATE, "ptmi_framebuffer_device_ptr: no framebuffer");
+  if (!c->peers.empty()) return fail(c, PTMI_ERR_UNSUPPORTED, "ptmi_framebuffer_device_ptr: a multi-device context has one buffer per GPU; use ptmi_read_framebuffer");
   *p = c->fb;
   if (bytes) *bytes = (size_t)c->W * c->H * 16;
   return PTMI_OK;
@@ -896,6 +1218,7 @@ int ptmi_framebuffer_device_ptr(ptmi_ctx* c, void** p, size_t* bytes) {
 int ptmi_bind_framebuffer(ptmi_ctx* c, void* dev_ptr, size_t bytes) {
   if (!c) return PTMI_ERR_INVALID_ARG;
   if (c->W <= 0) return fail(c, PTMI_ERR_STATE, "ptmi_bind_framebuffer: call ptmi_resize first");
+  if (!c->peers.empty()) return fail(c, PTMI_ERR_UNSUPPORTED, "ptmi_bind_framebuffer: not available on a multi-device context");
   if (!dev_ptr || ((uintptr_t)dev_ptr & 15) || bytes < (size_t)c->W * c->H * 16)
     return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_bind_framebuffer: need a 16-byte aligned device pointer of >= W*H*16 bytes");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -919,7 +1242,10 @@ int ptmi_resolve_rgba8(ptmi_ctx* c, float frame_num, uint8_t* dst, size_t bytes)
   if (bytes != npix * 4) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_resolve_rgba8: bytes != W*H*4");
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, c->d_scratch.ensure(bytes));
-  hipLaunchKernelGGL(k_resolve_rgba8, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->fb, (uint32_t)npix, frame_num,
+  float4* src = nullptr;
+  int gr = gather_framebuffer(c, &src);
+  if (gr) return gr;
+  hipLaunchKernelGGL(k_resolve_rgba8, dim3((unsigned)((npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, src, (uint32_t)npix, frame_num,
                      c->d_scratch.as<uchar4>());
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(dst, c->d_scratch.p, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -930,16 +1256,17 @@ int ptmi_resolve_rgba8(ptmi_ctx* c, float frame_num, uint8_t* dst, size_t bytes)
 int ptmi_set_counters(ptmi_ctx* c, int on) {
   if (!c) return PTMI_ERR_INVALID_ARG;
   c->counters = on != 0;
+  for (ptmi_ctx* q : c->peers) q->counters = c->counters;
   return PTMI_OK;
 }
 int ptmi_set_timing(ptmi_ctx* c, int on) {
   if (!c) return PTMI_ERR_INVALID_ARG;
-  c->timing = on < 0 ? 0 : (on > 2 ? 1 : on);
+  c->timing = (on < 0 || on > 5) ? 0 : on;
+  for (ptmi_ctx* q : c->peers) q->timing = c->timing;
   return PTMI_OK;
 }
 
-int ptmi_get_stats(ptmi_ctx* c, ptmi_stats* out) {
-  if (!c || !out) return PTMI_ERR_INVALID_ARG;
+static int get_stats_one(ptmi_ctx* c, ptmi_stats* out) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_spans(c);
@@ -951,18 +1278,45 @@ int ptmi_get_stats(ptmi_ctx* c, ptmi_stats* out) {
     c->stats.bvh_node_visits = t[7], c->stats.bvh_mat_fetches = t[8];
     if (t[15]) return fail(c, PTMI_ERR_STATE, "internal: a step's queue outgrew its buffer (paths were dropped)");
   }
+  c->stats.devices = 1;
   *out = c->stats;
   return PTMI_OK;
 }
 
-int ptmi_reset_stats(ptmi_ctx* c) {
-  if (!c) return PTMI_ERR_INVALID_ARG;
+int ptmi_get_stats(ptmi_ctx* c, ptmi_stats* out) {
+  if (!c || !out) return PTMI_ERR_INVALID_ARG;
+  int r = get_stats_one(c, out);
+  if (r) return r;
+  for (ptmi_ctx* q : c->peers) {  // counters add up over the local devices, times are the slowest device's
+    ptmi_stats s;
+    r = get_stats_one(q, &s);
+    if (r) return fail(c, r, q->err);
+    out->rays += s.rays, out->paths += s.paths, out->node_visits += s.node_visits, out->tri_tests += s.tri_tests;
+    out->sphere_tests += s.sphere_tests, out->quad_tests += s.quad_tests, out->mat_fetches += s.mat_fetches;
+    out->bvh_node_visits += s.bvh_node_visits, out->bvh_mat_fetches += s.bvh_mat_fetches;
+    out->intersect_launches += s.intersect_launches, out->shade_launches += s.shade_launches;
+    out->generate_launches += s.generate_launches, out->accumulate_launches += s.accumulate_launches;
+    out->render_ms = std::max(out->render_ms, s.render_ms), out->intersect_ms = std::max(out->intersect_ms, s.intersect_ms);
+    out->shade_ms = std::max(out->shade_ms, s.shade_ms), out->other_ms = std::max(out->other_ms, s.other_ms);
+    out->prims_ms = std::max(out->prims_ms, s.prims_ms), out->bvh_ms = std::max(out->bvh_ms, s.bvh_ms);
+    out->generate_ms = std::max(out->generate_ms, s.generate_ms), out->accumulate_ms = std::max(out->accumulate_ms, s.accumulate_ms);
+    out->devices += 1;
+  }
+  return PTMI_OK;
+}
+
+static int reset_stats_one(ptmi_ctx* c) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_spans(c);
   memset(&c->stats, 0, sizeof c->stats);
   if (c->d_totals.p) HIP_TRY(c, hipMemset(c->d_totals.p, 0, 16 * sizeof(unsigned long long)));
   return PTMI_OK;
+}
+
+int ptmi_reset_stats(ptmi_ctx* c) {
+  if (!c) return PTMI_ERR_INVALID_ARG;
+  return on_all_devices(c, reset_stats_one);
 }
 
 int ptmi_trace(ptmi_ctx* c, size_t n, const float* rays6, uint32_t* rng_inout, ptmi_hit* out) {

@@ -562,9 +562,11 @@ __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, Re
         const uint32_t want = max(region, cnt - n0);
         uint32_t nb = atomicAdd(&ctl[1].n_rays, want);
         if (nb + want > P.cap) {  // cannot happen with the host's sizing; never write out of bounds
+          // The survivors that still fit the current region are written as usual, the rest is dropped and the claim is
+          // handed back (every later claim overflows too and does the same, so the queue length ends up within the buffer);
+          // the host reports the flag as an error on the next synchronising call.
           atomicAdd(&totals[15], 1ull);
-          nb = 0;
-          s_n0 = 0;
+          atomicSub(&ctl[1].n_rays, want);
           s_b1 = 0xffffffffu;
         } else {
           s_b1 = nb;

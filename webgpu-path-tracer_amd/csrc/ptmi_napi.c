@@ -24,6 +24,8 @@ static void* g_lib;
 FN(ptmi_version)
 FN(ptmi_last_error)
 FN(ptmi_create)
+FN(ptmi_create_multi)
+FN(ptmi_prepare)
 FN(ptmi_destroy)
 FN(ptmi_default_params)
 FN(ptmi_set_params)
@@ -76,7 +78,7 @@ static int load_lib(char* err, size_t errlen) {
     snprintf(err, errlen, "libptmi.so lacks symbol " #name); \
     return -1;                                                \
   }
-  LOAD(ptmi_version) LOAD(ptmi_last_error) LOAD(ptmi_create) LOAD(ptmi_destroy) LOAD(ptmi_default_params) LOAD(ptmi_set_params)
+  LOAD(ptmi_version) LOAD(ptmi_last_error) LOAD(ptmi_create) LOAD(ptmi_create_multi) LOAD(ptmi_prepare) LOAD(ptmi_destroy) LOAD(ptmi_default_params) LOAD(ptmi_set_params)
   LOAD(ptmi_get_params) LOAD(ptmi_upload) LOAD(ptmi_resize) LOAD(ptmi_clear_framebuffer) LOAD(ptmi_set_shard) LOAD(ptmi_render_frame)
   LOAD(ptmi_render) LOAD(ptmi_synchronize) LOAD(ptmi_read_framebuffer) LOAD(ptmi_write_framebuffer) LOAD(ptmi_resolve_rgba8)
   LOAD(ptmi_set_counters) LOAD(ptmi_set_timing) LOAD(ptmi_get_stats) LOAD(ptmi_reset_stats) LOAD(ptmi_build_bvh) LOAD(ptmi_build_bvh_sah) LOAD(ptmi_build_bvh_device)
@@ -152,11 +154,34 @@ static napi_value js_version(napi_env env, napi_callback_info info) {
 static napi_value js_create(napi_env env, napi_callback_info info) {
   napi_value a[1];
   if (get_args(env, info, 1, a)) return NULL;
-  int32_t dev = 0;
-  CHECK_NAPI(napi_get_value_int32(env, a[0], &dev));
+  /* create(deviceId) = one GPU; create([id0, id1, ...]) = one context over several GPUs of the node (ptmi_create_multi):
+   * tiles sharded across them, one RCCL reduce inside readFramebuffer */
   ptmi_ctx* c = NULL;
-  int st = p_ptmi_create(&c, dev);
-  if (st) return throw_status(env, NULL, st, "ptmi_create");
+  bool is_array = false;
+  CHECK_NAPI(napi_is_array(env, a[0], &is_array));
+  if (is_array) {
+    uint32_t n = 0;
+    CHECK_NAPI(napi_get_array_length(env, a[0], &n));
+    if (n < 1 || n > 64) {
+      napi_throw_range_error(env, NULL, "create: need 1..64 device ids");
+      return NULL;
+    }
+    int ids[64];
+    for (uint32_t i = 0; i < n; i++) {
+      napi_value e;
+      int32_t v = 0;
+      CHECK_NAPI(napi_get_element(env, a[0], i, &e));
+      CHECK_NAPI(napi_get_value_int32(env, e, &v));
+      ids[i] = v;
+    }
+    int st = p_ptmi_create_multi(&c, ids, (int)n);
+    if (st) return throw_status(env, NULL, st, "ptmi_create_multi");
+  } else {
+    int32_t dev = 0;
+    CHECK_NAPI(napi_get_value_int32(env, a[0], &dev));
+    int st = p_ptmi_create(&c, dev);
+    if (st) return throw_status(env, NULL, st, "ptmi_create");
+  }
   ptmi_ctx** box = (ptmi_ctx**)malloc(sizeof *box);
   *box = c;
   napi_value ext;
@@ -363,6 +388,16 @@ static napi_value js_synchronize(napi_env env, napi_callback_info info) {
   return NULL;
 }
 
+static napi_value js_prepare(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (get_args(env, info, 1, a)) return NULL;
+  ptmi_ctx* c = ctx_of(env, a[0]);
+  if (!c) return NULL;
+  int st = p_ptmi_prepare(c);
+  if (st) return throw_status(env, c, st, "ptmi_prepare");
+  return NULL;
+}
+
 static napi_value js_read_fb(napi_env env, napi_callback_info info) {
   napi_value a[2];
   if (get_args(env, info, 2, a)) return NULL;
@@ -445,6 +480,9 @@ static napi_value js_stats(napi_env env, napi_callback_info info) {
   set_f64(env, o, "other_ms", s.other_ms);
   set_f64(env, o, "prims_ms", s.prims_ms);
   set_f64(env, o, "bvh_ms", s.bvh_ms);
+  set_f64(env, o, "generate_ms", s.generate_ms);
+  set_f64(env, o, "accumulate_ms", s.accumulate_ms);
+  set_f64(env, o, "devices", (double)s.devices);
   set_f64(env, o, "bvh_node_visits", (double)s.bvh_node_visits);
   set_f64(env, o, "bvh_mat_fetches", (double)s.bvh_mat_fetches);
   return o;
@@ -578,7 +616,7 @@ static napi_value init(napi_env env, napi_value exports) {
   } fns[] = {
       {"version", js_version}, {"create", js_create}, {"destroy", js_destroy}, {"defaultParams", js_default_params}, {"setParams", js_set_params},
       {"upload", js_upload}, {"resize", js_resize}, {"clear", js_clear}, {"setShard", js_set_shard}, {"renderFrame", js_render_frame},
-      {"render", js_render}, {"synchronize", js_synchronize}, {"readFramebuffer", js_read_fb}, {"writeFramebuffer", js_write_fb},
+      {"render", js_render}, {"synchronize", js_synchronize}, {"prepare", js_prepare}, {"readFramebuffer", js_read_fb}, {"writeFramebuffer", js_write_fb},
       {"resolveRGBA8", js_resolve}, {"setCounters", js_set_counters}, {"setTiming", js_set_timing}, {"stats", js_stats},
       {"resetStats", js_reset_stats}, {"buildBVH", js_build_bvh}, {"buildBVHSAH", js_build_bvh_sah}, {"buildBVHDevice", js_build_bvh_device}, {"parseObj", js_parse_obj},
   };

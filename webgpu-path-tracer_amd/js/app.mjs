@@ -27,7 +27,8 @@ async function main() {
     sc.native = loadNative();
     buffers = await sceneBuffers(sc);
   } else buffers = await sceneBuffers(c1Scene());
-  const backend = new Ptmi(Number(opt('device', 0)));
+  // --device N = one GPU; --devices a,b,.. = one context over several GPUs (ptmi_create_multi: tiles sharded, one RCCL reduce on read-back)
+  const backend = new Ptmi(opt('devices', null) ? opt('devices').split(',').map(Number) : Number(opt('device', 0)));
   const canvas = { wantPixels: false, pixels: null };
   const device = new GPUDeviceNode(backend, canvas);
   const camera = new Camera();

@@ -12,7 +12,8 @@ export function loadNative() {
 
 export const BUFFER_NAMES = ['spheres', 'quads', 'triangles', 'meshes', 'transforms', 'materials', 'bvh'];
 
-// One integrator context on one GPU (include/ptmi.h).
+// One integrator context (include/ptmi.h).  `device` is a GPU index, or an array of them: one context over several GPUs of
+// the node (ptmi_create_multi) — pixel tiles sharded across them, one RCCL reduce inside readFramebuffer().
 export class Ptmi {
   constructor(device = 0, native = loadNative()) {
     this.native = native;
@@ -30,6 +31,7 @@ export class Ptmi {
   renderFrame(uniforms20) { this.native.renderFrame(this.h, uniforms20); }
   render(view16, firstFrame, nFrames) { this.native.render(this.h, view16, firstFrame, nFrames); }
   synchronize() { this.native.synchronize(this.h); }
+  prepare() { this.native.prepare(this.h); }
   readFramebuffer(out = new Float32Array(this.width * this.height * 4)) { return this.native.readFramebuffer(this.h, out); }
   writeFramebuffer(src) { this.native.writeFramebuffer(this.h, src); }
   resolveRGBA8(frameNum, out = new Uint8Array(this.width * this.height * 4)) { return this.native.resolveRGBA8(this.h, frameNum, out); }

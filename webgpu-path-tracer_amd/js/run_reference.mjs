@@ -5,6 +5,7 @@
 //   node --experimental-loader ./ref_loader.mjs run_reference.mjs --frames 16 --out frame.ppm
 //
 //   --width/--height  canvas size (index.html: 900x600)     --frames N   animation frames to run
+//   --device N        GPU to use                            --devices a,b,..  ONE context over several GPUs (tiles sharded, RCCL reduce)
 //   --mock            record the backend calls instead of using a GPU (writes --dump <file.json>)
 //   --out file.ppm    tone-mapped image of the last frame   --raw file.f32  raw RGBA f32 framebuffer sum
 import fs from 'fs';
@@ -23,7 +24,7 @@ globalThis.performance = performance;
 async function main() {
   let backend;
   if (flag('mock')) backend = new (await import('./mock_backend.mjs')).MockBackend();
-  else backend = new (await import('./ptmi.mjs')).Ptmi(Number(opt('device', 0)));
+  else backend = new (await import('./ptmi.mjs')).Ptmi(opt('devices', null) ? opt('devices').split(',').map(Number) : Number(opt('device', 0)));
   const quiet = console.log;
   if (!flag('verbose')) console.log = () => {};
   const done = new Promise((resolve) => {

@@ -13,9 +13,9 @@ BUF = {"spheres": 1, "quads": 2, "triangles": 5, "meshes": 6, "transforms": 7, "
 
 # every symbol include/ptmi.h declares
 SYMBOLS = [
-    "ptmi_version", "ptmi_status_string", "ptmi_last_error", "ptmi_create", "ptmi_destroy", "ptmi_default_params",
+    "ptmi_version", "ptmi_status_string", "ptmi_last_error", "ptmi_create", "ptmi_create_multi", "ptmi_destroy", "ptmi_default_params",
     "ptmi_set_params", "ptmi_get_params", "ptmi_upload", "ptmi_resize", "ptmi_clear_framebuffer", "ptmi_set_shard",
-    "ptmi_render_frame", "ptmi_render", "ptmi_synchronize", "ptmi_read_framebuffer", "ptmi_write_framebuffer",
+    "ptmi_render_frame", "ptmi_render", "ptmi_synchronize", "ptmi_prepare", "ptmi_read_framebuffer", "ptmi_write_framebuffer",
     "ptmi_framebuffer_device_ptr", "ptmi_bind_framebuffer", "ptmi_stream", "ptmi_resolve_rgba8", "ptmi_set_counters",
     "ptmi_set_timing", "ptmi_get_stats", "ptmi_reset_stats", "ptmi_trace", "ptmi_math_eval", "ptmi_build_bvh",
     "ptmi_build_bvh_sah", "ptmi_build_bvh_device", "ptmi_obj_parse", "ptmi_free",
@@ -34,7 +34,8 @@ class Stats(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint64) for n in (
         "rays", "paths", "node_visits", "tri_tests", "sphere_tests", "quad_tests", "mat_fetches", "frames",
         "intersect_launches", "shade_launches", "bvh_node_visits", "bvh_mat_fetches")] + [
-        (n, ctypes.c_double) for n in ("render_ms", "intersect_ms", "shade_ms", "other_ms", "prims_ms", "bvh_ms")]
+        (n, ctypes.c_double) for n in ("render_ms", "intersect_ms", "shade_ms", "other_ms", "prims_ms", "bvh_ms", "generate_ms", "accumulate_ms")] + [
+        (n, ctypes.c_uint64) for n in ("generate_launches", "accumulate_launches", "devices")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -73,6 +74,8 @@ def load_library(build=False):
     L.ptmi_last_error.restype = ctypes.c_char_p
     L.ptmi_last_error.argtypes = [vp]
     L.ptmi_create.argtypes = [ctypes.POINTER(vp), i32]
+    L.ptmi_create_multi.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int), i32]
+    L.ptmi_prepare.argtypes = [vp]
     L.ptmi_destroy.argtypes = [vp]
     L.ptmi_destroy.restype = None
     L.ptmi_default_params.argtypes = [ctypes.POINTER(Params)]
@@ -175,12 +178,17 @@ class NativeHost:
 
 
 class Context:
-    """One integrator context on one GPU (mirrors the reference's Renderer+WebGPU pair for the hot path)."""
+    """One integrator context (mirrors the reference's Renderer+WebGPU pair for the hot path).  `device` is a GPU index, or a
+    list of them for a multi-device context (ptmi_create_multi: tiles sharded across the GPUs, one RCCL reduce on read-back)."""
 
     def __init__(self, device=0):
         self.lib = load_library()
         h = ctypes.c_void_p()
-        st = self.lib.ptmi_create(ctypes.byref(h), device)
+        if isinstance(device, (list, tuple)):
+            ids = (ctypes.c_int * len(device))(*[int(d) for d in device])
+            st = self.lib.ptmi_create_multi(ctypes.byref(h), ids, len(device))
+        else:
+            st = self.lib.ptmi_create(ctypes.byref(h), device)
         if st != 0:
             raise PtmiError(st, self.lib.ptmi_last_error(None).decode())
         self.h = h
@@ -247,6 +255,10 @@ class Context:
     def synchronize(self):
         self._ck(self.lib.ptmi_synchronize(self.h))
 
+    def prepare(self):
+        """Validate the uploaded scene and build the device-side digests now (otherwise the first render does it)."""
+        self._ck(self.lib.ptmi_prepare(self.h))
+
     def read_framebuffer(self):
         out = np.empty((self.height, self.width, 4), np.float32)
         self._ck(self.lib.ptmi_read_framebuffer(self.h, _ptr(out), out.nbytes))
@@ -278,7 +290,7 @@ class Context:
         self._ck(self.lib.ptmi_set_counters(self.h, int(on)))
 
     def set_timing(self, mode):
-        """0/False off, 1/True every kernel, 2 only k_bvh."""
+        """0/False off, 1/True every kernel, 2 / 3 / 4 / 5 only k_bvh / k_shade / k_generate / k_accumulate."""
         self._ck(self.lib.ptmi_set_timing(self.h, int(mode)))
 
     def stats(self):
