@@ -114,10 +114,18 @@ def make_context(pkg, wl, device, args):
 
 # ---------------------------------------------------------------------------------------------------- rocprofv3 passes
 PMC_PASSES = (
-    ("sq", "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY"),
-    ("fetch", "FETCH_SIZE"),
+    ("sq", "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_TRANS_F64"),
+    ("fetch", "FETCH_SIZE SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32"),
     ("write", "WRITE_SIZE"),
 )
+# Issue cost of a wave64 instruction on one SIMD, measured by tools/valu_peak.hip (profiles/valu_peak.json, throughput at 4-8 waves
+# per SIMD): 2 cycles for f32 add/mul/fma (and mov, and/or/xor, integer add), 4 for min/max, compares, shifts, conversions, integer
+# multiplies, packed f32, f64 arithmetic and the v_div_* helpers, 8 for f32 transcendentals, 16 for v_rcp_f64.  The counters
+# can tell the 2-, 8- and 16-cycle classes apart; everything else is charged 4 (moves and integer adds too: an over-estimate).
+def issue_cycles(p, L):
+    fast = (p.get("SQ_INSTS_VALU_ADD_F32", 0.0) + p.get("SQ_INSTS_VALU_MUL_F32", 0.0) + p.get("SQ_INSTS_VALU_FMA_F32", 0.0)) / max(p.get("launches_fetch", L), 1)
+    n, t32, t64 = p["SQ_INSTS_VALU"] / L, p.get("SQ_INSTS_VALU_TRANS_F32", 0.0) / L, p.get("SQ_INSTS_VALU_TRANS_F64", 0.0) / L
+    return 4.0 * n - 2.0 * min(fast, n) + 4.0 * t32 + 12.0 * t64
 
 
 def pmc_child(args):
@@ -188,12 +196,14 @@ def kernel_table(split, steps_in_split, pmc):
             L = p["launches_sq"]
             cyc = p["SQ_BUSY_CYCLES"] / 32.0 / L                      # kernel cycles per launch (the counter is summed over 8 XCDs x 4 SEs)
             clock = cyc / (p["pmc_ms_sq"] / L * 1e-3) if p["pmc_ms_sq"] else 0.0
-            busy = 4.0 * p["SQ_ACTIVE_INST_VALU"] / N_SIMD / L        # SQ_ACTIVE_INST_* count quad-cycles; average per SIMD
+            busy = issue_cycles(p, L) / N_SIMD                        # issue cycles of this kernel's instruction mix, per SIMD and launch
+            busy4 = 4.0 * p["SQ_ACTIVE_INST_VALU"] / N_SIMD / L       # SQ_ACTIVE_INST_VALU counts quad-cycles, at least one per instruction
             live_cyc = (ms / n * 1e-3) * clock if n and clock else cyc
             e.update({
                 "valu_instr_per_launch": p["SQ_INSTS_VALU"] / L,
                 "valu_busy_frac": min(1.0, busy / live_cyc) if live_cyc else None,
-                "avg_cycles_per_valu_instr": 4.0 * p["SQ_ACTIVE_INST_VALU"] / p["SQ_INSTS_VALU"] if p["SQ_INSTS_VALU"] else None,
+                "valu_busy_frac_4_cycles_per_instr": min(1.0, busy4 / live_cyc) if live_cyc else None,
+                "avg_cycles_per_valu_instr": issue_cycles(p, L) / (p["SQ_INSTS_VALU"] / L) if p["SQ_INSTS_VALU"] else None,
                 "wave_wait_frac": p["SQ_WAIT_ANY"] / p["SQ_WAVE_CYCLES"] if p["SQ_WAVE_CYCLES"] else None,
                 "active_lane_frac": p["SQ_THREAD_CYCLES_VALU"] / (64.0 * p["SQ_ACTIVE_INST_VALU"]) if p["SQ_ACTIVE_INST_VALU"] else None,
                 "clock_ghz_in_pmc_pass": clock / 1e9,
@@ -227,9 +237,9 @@ def roofline_of(tab, dom, timed_ms_per_launch, timed_launches):
     else:
         rate = e["valu_instr_per_launch"] / (timed_ms_per_launch * 1e-3) / 1e9
         r.update({"bound": "valu_issue", "achieved": rate, "peak": rate / vf if vf else None, "unit": "G wave-instr/s", "frac": vf,
-                  "peak_definition": "the rate at which this kernel's own instruction mix issues when no SIMD is ever idle: instructions / "
-                                     "(4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs) x clock; the mix averages %.2f cycles per wave64 instruction "
-                                     "(profiles/valu_peak.json: 2 for f32 fma/mul/add/mov, 4 for min/max/cmp/shift/cvt/f64/packed, 8 for f32 transcendentals, 16 for v_rcp_f64)"
+                  "peak_definition": "the rate at which this kernel's own instruction mix issues when no SIMD is ever idle: 1024 SIMDs x clock / "
+                                     "(average issue cycles per wave64 instruction = %.2f: 2 for f32 add/mul/fma, 8 for f32 transcendentals, 16 for v_rcp_f64, 4 for "
+                                     "everything else — classes measured by tools/valu_peak.hip, profiles/valu_peak.json; class counts from this run's SQ_INSTS_VALU_* counters)"
                                      % (e.get("avg_cycles_per_valu_instr") or 0.0)})
     if max(vf or 0.0, hf or 0.0) < 0.5:
         r["bound_note"] = "neither the VALU nor HBM is busy half the time: the kernel waits on memory latency (wave_wait_frac %.2f)" % (e.get("wave_wait_frac") or 0.0)
@@ -300,7 +310,7 @@ def cpu_baseline(pkg, wl, spp, args):
 
     def sample(threads, seconds, rows):
         # rows = how many image rows the probe frame covers (the single-thread sample is bounded by a pixel window)
-        pr = None if rows >= H else (0, rows * W)
+        pr = (0, -1) if rows >= H else (0, rows * W)
         t = time.perf_counter()
         _, ost = ptm_oracle.render(buffers, W, H, view, 1, 1, threads=threads, pixel_range=pr, **kw)
         one = time.perf_counter() - t
@@ -309,7 +319,7 @@ def cpu_baseline(pkg, wl, spp, args):
         _, ost = ptm_oracle.render(buffers, W, H, view, 1, frames, threads=threads, pixel_range=pr, **kw)
         cdt = time.perf_counter() - t
         what = "same scene and camera, %dx%d%s, frames 1..%d of %d (%d rays), scalar f32 oracle%s" % (
-            W, H, "" if pr is None else ", pixel rows 0..%d" % (rows - 1), frames, spp, ost["rays"], " with OpenMP over pixels" if threads > 1 else ", one thread")
+            W, H, "" if rows >= H else ", pixel rows 0..%d" % (rows - 1), frames, spp, ost["rays"], " with OpenMP over pixels" if threads > 1 else ", one thread")
         return ost["rays"] / cdt / 1e6, what
 
     v, what = sample(cores, args.cpu_seconds, H)

@@ -86,7 +86,7 @@ struct ptmi_ctx {
   bool pixsum_alloc = false;
   size_t slot_cap = 0;  // slots per queue buffer (paths + room for the holes k_shade's regions leave)
   DBuf d_q0[2], d_q1[2], d_q2[2], d_tp[2], d_hm[2];  // slot-indexed live state and hit records, ping-pong
-  DBuf d_uv, d_acc, d_pixsum, d_ctl, d_totals, d_scratch, d_spill, d_heads;
+  DBuf d_uv, d_acc, d_pixsum, d_touched, d_ctl, d_totals, d_scratch, d_spill, d_heads;
   int ctl_cap = 0;
 
   // Render-ahead of ptmi_render_frame (see there): per-frame colours of frames [frame0, frame0 + count) sit in d_acc,
@@ -441,6 +441,7 @@ int ensure_paths(ptmi_ctx* c, size_t npaths, int n_ctl, bool need_pixsum) {
     }
     HIP_TRY(c, c->d_uv.ensure(slots * 8));
     HIP_TRY(c, c->d_acc.ensure(npaths * 16));
+    HIP_TRY(c, c->d_touched.ensure(npaths));
     c->path_cap = npaths;
     c->slot_cap = slots;
     c->pixsum_alloc = false;
@@ -472,6 +473,7 @@ Paths paths_of(ptmi_ctx* c, int step, bool with_pixsum) {
   P.uv = c->d_uv.as<float2>();
   P.acc = c->d_acc.as<float4>();
   P.pixsum = with_pixsum ? c->d_pixsum.as<float4>() : nullptr;
+  P.touched = with_pixsum ? nullptr : c->d_touched.as<uint8_t>();  // NUM_SAMPLES == 1: acc[pid] is written lazily
   P.cap = (uint32_t)c->slot_cap;
   return P;
 }
@@ -587,6 +589,7 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   HIP_TRY(c, hipMemsetAsync(ctl, 0, (size_t)(n_steps + 2) * sizeof(StepCtl), c->stream));
   {
     ScopedSpan s(c, T_GENERATE);
+    if (rc.num_samples == 1) HIP_TRY(c, hipMemsetAsync(c->d_touched.p, 0, npaths, c->stream));
     if (c->counters) hipLaunchKernelGGL(k_generate<true>, dim3(ew_grid), dim3(kBlock), 0, c->stream, c->S, rc, paths_of(c, 0, rc.num_samples > 1), ctl, c->d_heads.as<uint32_t>(), tot);
     else hipLaunchKernelGGL(k_generate<false>, dim3(ew_grid), dim3(kBlock), 0, c->stream, c->S, rc, paths_of(c, 0, rc.num_samples > 1), ctl, c->d_heads.as<uint32_t>(), tot);
     HIP_TRY(c, hipGetLastError());
@@ -608,7 +611,7 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
     }
     {
       ScopedSpan sp(c, T_SHADE);
-#define PTMI_LAUNCH_SHADE(IS, SO, CN) hipLaunchKernelGGL((k_shade<IS, SO, CN>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, c->d_heads.as<uint32_t>(), tot)
+#define PTMI_LAUNCH_SHADE(IS, SO, CN) hipLaunchKernelGGL((k_shade<IS, SO, CN>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, c->d_heads.as<uint32_t>(), tot, s == 0 ? 1 : 0)
 #define PTMI_LAUNCH_SHADE2(IS, SO) \
   do {                             \
     if (c->counters) PTMI_LAUNCH_SHADE(IS, SO, true); \
@@ -630,7 +633,7 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   }
   {
     ScopedSpan s(c, T_ACCUM);
-    hipLaunchKernelGGL(k_accumulate, dim3(ew_grid), dim3(kBlock), 0, c->stream, rc, paths_of(c, 0, false), c->fb, ctl, n_steps, tot, 0,
+    hipLaunchKernelGGL(k_accumulate, dim3(ew_grid), dim3(kBlock), 0, c->stream, rc, paths_of(c, 0, rc.num_samples > 1), c->fb, ctl, n_steps, tot, 0,
                        fold < 0 ? n_frames : std::min(fold, n_frames));
     c->stats.accumulate_launches++;
   }
@@ -946,7 +949,7 @@ void ptmi_destroy(ptmi_ctx* c) {
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (DBuf* b : {&c->d_quad_unit_n, &c->d_spheres, &c->d_sphere_info, &c->d_quads, &c->d_quad_mat, &c->d_tris, &c->d_pretri, &c->d_meshes, &c->d_xforms,
                   &c->d_mats, &c->d_pairs, &c->d_leaf_table, &c->d_fb_own, &c->d_q0[0], &c->d_q0[1], &c->d_q1[0], &c->d_q1[1], &c->d_q2[0],
-                  &c->d_q2[1], &c->d_tp[0], &c->d_tp[1], &c->d_hm[0], &c->d_hm[1], &c->d_uv, &c->d_acc, &c->d_pixsum, &c->d_ctl, &c->d_totals,
+                  &c->d_q2[1], &c->d_tp[0], &c->d_tp[1], &c->d_hm[0], &c->d_hm[1], &c->d_uv, &c->d_acc, &c->d_pixsum, &c->d_touched, &c->d_ctl, &c->d_totals,
                   &c->d_scratch, &c->d_spill, &c->d_heads, &c->d_fb_gather, &c->d_fb_stage})
     b->release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1069,7 +1072,7 @@ static int render_frame_one(ptmi_ctx* c, const float* u) {
   c->last_frame = k;
   memcpy(c->last_view, view, 64);
   if (A.valid && follows && A.next < A.count && k == A.frame0 + (uint32_t)A.next && memcmp(view, A.view, 64) == 0) {
-    hipLaunchKernelGGL(k_accumulate, dim3(A.grid), dim3(kBlock), 0, c->stream, A.rc, paths_of(c, 0, false), c->fb, c->d_ctl.as<StepCtl>(), 0,
+    hipLaunchKernelGGL(k_accumulate, dim3(A.grid), dim3(kBlock), 0, c->stream, A.rc, paths_of(c, 0, A.rc.num_samples > 1), c->fb, c->d_ctl.as<StepCtl>(), 0,
                        c->d_totals.as<unsigned long long>(), A.next, A.next + 1);
     HIP_TRY(c, hipGetLastError());
     A.next++;

@@ -163,6 +163,8 @@ struct Paths {
   float2* uv;        // by slot of `in`: barycentrics, written by k_bvh and read by k_shade for triangle hits only
   float4* acc;       // by path id: {acc_radiance.xyz, sample index as int bits}; the final pixel colour at the end
   float4* pixsum;    // by path id: {pixColor.xyz, -}  (num_samples > 1 only)
+  uint8_t* touched;  // by path id, NUM_SAMPLES == 1 only (else null): 0 = acc[pid] has never been written and stands for (0,0,0) — the
+                     // batch starts with one small memset of these flags instead of k_generate streaming 16 bytes of zeros per path
   uint32_t cap;      // slots per queue buffer
 };
 

@@ -56,13 +56,16 @@ __global__ __launch_bounds__(kBlock) void k_generate(DevScene S, RenderConst rc,
     float2 tp = make_float2(0.0f, 0.0f);
     uint32_t hm = HITMAT_MISS;
     if (trace) prims_for_ray<COUNT>(S, o, d, rng, tp, hm, cn);
+    // 44 bytes per path.  What every new path starts with — throughput (1,1,1), bounce 0, acc_radiance 0 — is not stored: step 0's
+    // k_shade is told so (`first`), and acc[pid] counts as zero until P.touched[pid] is set (NUM_SAMPLES == 1).
     P.in.q0[g] = make_float4(o.x, o.y, o.z, __uint_as_float(rng));
     P.in.q1[g] = make_float4(d.x, d.y, d.z, __uint_as_float(pid));
-    P.in.q2[g] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0));
     P.hin.tp[g] = tp;
     P.hin.mat[g] = hm;
-    P.acc[pid] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(0));
-    if (P.pixsum) P.pixsum[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (!P.touched) {
+      P.acc[pid] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(0));
+      P.pixsum[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) ctl[0].n_rays = total;
   if (COUNT) reduce_counters(cn, totals, false);
@@ -278,15 +281,25 @@ struct SlotState {
   float2 tp;
   uint32_t hitmat, slot;
 };
-DEV SlotState load_slot(const Paths& P, uint32_t slot) {
+DEV SlotState load_slot(const Paths& P, uint32_t slot, bool first) {
   SlotState st;
   st.slot = slot;
   st.hitmat = P.hin.mat[slot];
   st.q1 = P.in.q1[slot];
   st.q0 = P.in.q0[slot];
-  st.q2 = P.in.q2[slot];
+  if (first) st.q2 = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0));  // step 0: k_generate does not store what every path starts with
+  else st.q2 = P.in.q2[slot];
   st.tp = P.hin.tp[slot];
   return st;
+}
+// acc_radiance of a path as ray_color sees it; never-written entries stand for zero (P.touched, NUM_SAMPLES == 1)
+DEV float4 acc_load(const Paths& P, uint32_t pid) {
+  if (P.touched && !P.touched[pid]) return make_float4(0.0f, 0.0f, 0.0f, __int_as_float(0));
+  return P.acc[pid];
+}
+DEV void acc_store(const Paths& P, uint32_t pid, float4 v) {
+  P.acc[pid] = v;
+  if (P.touched) P.touched[pid] = 1;
 }
 
 template <bool IS>
@@ -382,9 +395,9 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
   ns.pid = pid;
   if (!sample_done) {
     if (changes) {
-      float4 A4 = P.acc[pid];
+      float4 A4 = acc_load(P, pid);
       f3 acc = mk3(A4) + add;
-      P.acc[pid] = make_float4(acc.x, acc.y, acc.z, A4.w);
+      acc_store(P, pid, make_float4(acc.x, acc.y, acc.z, A4.w));
     }
     ns.o = no, ns.d = nd, ns.T = T, ns.bounce = bounce, ns.rng = rng;
     return true;
@@ -394,12 +407,12 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
   if (rc.num_samples == 1) {
     if (drop_acc) {
       f3 fin = (mk3(0, 0, 0) + add) / rc.sample_div;
-      P.acc[pid] = make_float4(fin.x, fin.y, fin.z, __int_as_float(1));
+      acc_store(P, pid, make_float4(fin.x, fin.y, fin.z, __int_as_float(1)));
     } else if (changes) {
-      float4 A4 = P.acc[pid];
+      float4 A4 = acc_load(P, pid);
       f3 fin = (mk3(0, 0, 0) + (mk3(A4) + add)) / rc.sample_div;
-      P.acc[pid] = make_float4(fin.x, fin.y, fin.z, __int_as_float(1));
-    }  // else: (0 + acc) / 1 == acc, already in place
+      acc_store(P, pid, make_float4(fin.x, fin.y, fin.z, __int_as_float(1)));
+    }  // else: (0 + acc) / 1 == acc, already in place — or never written, which k_accumulate reads as zero
     return false;
   }
   float4 A4 = P.acc[pid];
@@ -432,7 +445,7 @@ constexpr int kSChunk = 512;  // slots a k_shade block sorts, shades and compact
 //      the next region — and marks what is left at the end as holes.
 template <bool IS, bool SORT, bool COUNT>
 __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads,
-                                                                  unsigned long long* __restrict__ totals) {
+                                                                  unsigned long long* __restrict__ totals, int first) {
   reset_heads(heads);
   __shared__ float4 s_q0[kSChunk], s_q1[kSChunk], s_q2[kSChunk];
   __shared__ uint16_t s_sorted[SORT ? kSChunk : 1];
@@ -526,7 +539,7 @@ __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, Re
         ns.o = ns.d = ns.T = mk3(0, 0, 0);
         ns.bounce = 0, ns.rng = 0, ns.pid = 0;
         if (k < nvalid) {
-          const SlotState st = load_slot(P, base + s_sorted[k]);
+          const SlotState st = load_slot(P, base + s_sorted[k], first != 0);
           survive = shade_one<IS>(S, rc, P, st, L, ns);
         }
         stage(survive, ns);
@@ -541,7 +554,7 @@ __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, Re
         ns.o = ns.d = ns.T = mk3(0, 0, 0);
         ns.bounce = 0, ns.rng = 0, ns.pid = 0;
         if (j < m) {
-          const SlotState st = load_slot(P, base + j);
+          const SlotState st = load_slot(P, base + j, first != 0);
           valid = __float_as_uint(st.q1.w) != PID_HOLE;
           if (valid) survive = shade_one<IS>(S, rc, P, st, L, ns);
         }
@@ -618,8 +631,9 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(RenderConst rc, Paths P, 
     float4 cur = fb[pix];
     f3 c = mk3(cur);
     for (int f = f_begin; f < f_end; f++) {
-      float4 a = P.acc[(size_t)f * rc.n_local + j];
-      f3 col = mk3(a);
+      const size_t pid = (size_t)f * rc.n_local + j;
+      f3 col = mk3(0, 0, 0);  // a path that never wrote its acc_radiance returned (0,0,0)
+      if (!P.touched || P.touched[pid]) col = mk3(P.acc[pid]);
       if (f == 0 && rc.reset_first) {
         c = col;
       } else {
