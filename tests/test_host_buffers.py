@@ -86,6 +86,31 @@ def test_cameras_match_reference_js(pkg):
         assert _same(pkg.scenes.camera_view(eye, center), np.array(man[k]["viewMatrix"], np.float32)), k
 
 
+def test_camera_interaction_matches_reference_js(pkg):
+    """lib/camera.js:35-131 — wheel zoom, drag orbit (anchor fixed at mousedown), arrow keys, flags — replayed on the Python mirror
+    against the sequence captured from the reference's own Camera under Node (oracle/capture/capture_camera.mjs), bit for bit."""
+    import json
+    import os
+
+    from conftest import ROOT
+    from webgpu_path_tracer_amd.host.scene import Camera
+
+    steps = json.load(open(os.path.join(ROOT, "tests", "golden", "camera_sequence.json")))["steps"]
+    assert len(steps) >= 30 and {s["op"]["kind"] for s in steps} == {"set_camera", "wheel", "keydown", "mousedown", "mousemove", "mouseup"}
+    cam = Camera()
+    for i, g in enumerate(steps):
+        o = dict(g["op"])
+        kind = o.pop("kind")
+        if kind == "set_camera":
+            cam.set_camera(o["eye"], o["center"], o["up"])
+        else:
+            cam.dispatch(kind, **o)
+        for name in ("eye", "center", "direction", "viewMatrix"):
+            got = np.asarray(getattr(cam, name), np.float32).view(np.uint32)
+            assert np.array_equal(got, np.array(g[name], np.uint32)), (i, g["op"], name)
+        assert (cam.MOVING, cam.keyPress) == (g["MOVING"], g["keyPress"]) and cam.rotateAngle == g["rotateAngle"], (i, g["op"])
+
+
 def test_gl_matrix_known_answers(pkg):
     """gl-matrix boundary is unpinned by the reference (CDN import): closed-form checks."""
     from webgpu_path_tracer_amd.host.glmatrix import mat4, vec3

@@ -70,6 +70,13 @@ def test_unchanged_reference_app_runs_on_the_shim(tmp_path, pkg):
 
 
 @needs_node
+def test_js_camera_interaction_matches_reference_js():
+    """The shipped Camera (js/lib/scene.mjs) with its own event wiring against the sequence captured from the reference's lib/camera.js."""
+    rep = json.loads(_run([node, "check_camera.mjs", os.path.join(ROOT, "tests", "golden", "camera_sequence.json")], cwd=JS))
+    assert rep["ok"] and rep["steps"] >= 30, rep["firstBad"]
+
+
+@needs_node
 def test_wgsl_header_constants_become_params():
     src = "import {paramsFromWGSL} from './webgpu_node.mjs'; console.log(JSON.stringify(paramsFromWGSL('const NUM_SAMPLES = 4;\\nconst MAX_BOUNCES = 8;\\nconst STRATIFY = true;\\nconst IMPORTANCE_SAMPLING = false;\\nconst STACK_SIZE = 24;\\n let background_color = vec3f(0.5, 0, 1);')))"
     f = os.path.join(JS, "_t.mjs")

@@ -394,6 +394,7 @@ class Camera:
         self.zoomSpeed, self.moveSpeed, self.keypressMoveSpeed = 0.1, 0.01, 0.1
         self.MOVING = 0
         self.keyPress = 0
+        self.rotateAngle = 0
 
     def set_camera(self, eye=None, center=None, up=None):  # lib/camera.js:25-33
         eye = self.eye if eye is None else eye
@@ -415,8 +416,53 @@ class Camera:
 
     def move(self, oldCoord, newCoord):  # lib/camera.js:44-53
         dX = (newCoord[0] - oldCoord[0]) * math.pi / 180 * self.moveSpeed
+        self.rotateAngle = dX
         vec3.rotateY(self.eye, self.eye, [0, 0, 0], dX)
         self.set_camera()
+
+    def _shift(self, axis, d):  # lib/camera.js:55-74: eye and center move together along x (left/right) or y (up/down)
+        e = [float(v) for v in self.eye]
+        c = [float(v) for v in self.center]
+        e[axis] += d
+        c[axis] += d
+        vec3.set(self.eye, e[0], e[1], e[2])
+        vec3.set(self.center, c[0], c[1], c[2])
+        self.set_camera()
+
+    def moveLeft(self):
+        self._shift(0, +self.keypressMoveSpeed)
+
+    def moveRight(self):
+        self._shift(0, -self.keypressMoveSpeed)
+
+    def moveUp(self):
+        self._shift(1, -self.keypressMoveSpeed)
+
+    def moveDown(self):
+        self._shift(1, +self.keypressMoveSpeed)
+
+    def dispatch(self, kind, **ev):
+        """The listeners Camera.MoveCamera installs on the canvas / document (lib/camera.js:77-131), as one entry point:
+        kind in {"wheel", "mousedown", "mousemove", "mouseup", "keydown"}; ev carries the DOM event's fields."""
+        if kind == "wheel":
+            self.zoom(ev.get("deltaY") or ev.get("detail") or ev.get("wheelDelta") or 0)
+            self.keyPress = 1
+        elif kind == "mousedown":
+            if ev.get("button", 0) == 0:
+                self._drag_from = [ev["x"], ev["y"]]  # stays the anchor for the whole drag: the reference never updates oldCoord
+                self._dragging = True
+        elif kind == "mousemove":
+            if getattr(self, "_dragging", False):
+                self.move(self._drag_from, [ev["x"], ev["y"]])
+                self.MOVING = 1
+        elif kind == "mouseup":
+            self._dragging = False
+            self.MOVING = 0
+        elif kind == "keydown":
+            fn = {"ArrowLeft": self.moveLeft, "ArrowRight": self.moveRight, "ArrowUp": self.moveUp, "ArrowDown": self.moveDown}.get(ev.get("key"))
+            if fn:
+                fn()
+                self.keyPress = 1
 
 
 def uniforms_array(width, height, frame_num, reset_buffer, view_matrix):

@@ -217,11 +217,25 @@ export class Scene {   // lib/scene.js surface; subclasses or callers fill creat
 }
 
 export class Camera {   // lib/camera.js (interaction handlers are attached only when a canvas is given)
-  constructor(canvas = null) {
+  constructor(canvas = null, doc = (typeof document !== 'undefined' ? document : null)) {
     this.viewMatrix = mat4.create();
     this.eye = vec3.create(); this.center = vec3.create(); this.up = vec3.create(); this.direction = vec3.create();
     this.rotateAngle = 0; this.zoomSpeed = 0.1; this.moveSpeed = 0.01; this.keypressMoveSpeed = 0.1;
     this.MOVING = 0; this.keyPress = 0;
+    if (canvas) this.attach(canvas, doc);
+  }
+  // lib/camera.js:77-131: drag with the left button orbits about the y axis (the anchor stays where the button went down),
+  // the wheel zooms, the arrow keys shift eye and center together
+  attach(canvas, doc) {
+    let anchor = [];
+    const onMove = (ev) => { this.move(anchor, [ev.clientX, ev.clientY]); this.MOVING = 1; };
+    canvas.addEventListener('mousedown', (ev) => { if (ev.button == 0) { anchor = [ev.clientX, ev.clientY]; canvas.addEventListener('mousemove', onMove); } });
+    canvas.addEventListener('mouseup', () => { canvas.removeEventListener('mousemove', onMove); this.MOVING = 0; });
+    canvas.addEventListener('wheel', (ev) => { this.zoom(ev.deltaY || ev.detail || ev.wheelDelta); this.keyPress = 1; });
+    if (doc) doc.addEventListener('keydown', (ev) => {
+      const fn = { ArrowLeft: 'moveLeft', ArrowRight: 'moveRight', ArrowUp: 'moveUp', ArrowDown: 'moveDown' }[ev.key];
+      if (fn) { this[fn](); this.keyPress = 1; }
+    });
   }
   set_camera(eye = this.eye, center = this.center, up = this.up) {   // lib/camera.js:25-33
     vec3.set(this.eye, eye[0], eye[1], eye[2]);
