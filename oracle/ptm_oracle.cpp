@@ -841,6 +841,27 @@ int ptmo_math(int fn, int64_t n, const float* x, const float* y, float* out) {
   return 0;
 }
 
+/* The display pass (shaders/fragment.js:22-36 with aces_approx, shaders/common.wgsl:273-282): color = framebuffer.xyz / frameNum,
+ * ACES approximation, pow(color, 1/2.2) — the exponent is an abstract-float constant expression, folded in f64 and rounded once —,
+ * then the canvas's unorm8 store (round to nearest, value * 255 + 0.5 truncated).  Alpha is 1.  out = npix x RGBA8. */
+int ptmo_resolve_rgba8(const float* fb, int64_t npix, float frame_num, uint8_t* out) {
+  const float inv_gamma = (float)(1 / 2.2);
+  for (int64_t i = 0; i < npix; i++) {
+    for (int k = 0; k < 3; k++) {
+      float v = fb[4 * i + k] / frame_num;
+      float v1 = v * 0.6f;
+      float a = (v1 * (2.51f * v1 + 0.03f)) / (v1 * (2.43f * v1 + 0.59f) + 0.14f);
+      a = ptm_min(ptm_max(a, 0.0f), 1.0f); /* clamp(x, 0, 1) = min(max(x, 0), 1) */
+      float g = ptm_pow(a, inv_gamma);
+      float s = g * 255.0f + 0.5f;
+      s = ptm_min(ptm_max(s, 0.0f), 255.0f);
+      out[4 * i + k] = (uint8_t)s;
+    }
+    out[4 * i + 3] = 255;
+  }
+  return 0;
+}
+
 int ptmo_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

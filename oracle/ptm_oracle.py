@@ -149,5 +149,17 @@ def math_eval(fn, x, y=None):
     return out
 
 
+def resolve_rgba8(fb, frame_num):
+    """The display pass on the CPU: (H,W,4) f32 framebuffer sum -> (H,W,4) uint8."""
+    a = np.ascontiguousarray(fb, np.float32)
+    out = np.empty(a.shape[:-1] + (4,), np.uint8)
+    L = lib()
+    L.ptmo_resolve_rgba8.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p]
+    rc = L.ptmo_resolve_rgba8(_ptr(a), a.size // 4, float(frame_num), _ptr(out))
+    if rc != 0:
+        raise RuntimeError("ptmo_resolve_rgba8 failed (%d)" % rc)
+    return out
+
+
 def max_threads():
     return lib().ptmo_max_threads()

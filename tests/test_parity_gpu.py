@@ -218,16 +218,24 @@ def test_full_size_properties_1080p(ctx, pkg, oracle):
     assert_same_bits(a.reshape(-1, 4)[p0 : p0 + 6000], want.reshape(-1, 4)[p0 : p0 + 6000], "1080p crop")
 
 
-def test_resolve_rgba8(ctx, pkg):
+def test_resolve_rgba8(ctx, pkg, oracle):
+    """The display pass, byte for byte against the oracle's restatement (same ptm_pow), on a rendered image and on a sweep of
+    values incl. negatives, > 1 after tone mapping, NaN and inf; a float64 evaluation of fragment.js stays within one level."""
     _setup(ctx, pkg, "c1", 64, 64, max_bounces=4)
     ctx.render(cornell_view(pkg), 1, 4)
     fb = ctx.read_framebuffer()
     img = ctx.resolve_rgba8(4)
+    assert img.shape == (64, 64, 4) and (img[..., 3] == 255).all()
+    assert np.array_equal(img, oracle.resolve_rgba8(fb, 4))
     c = fb[..., :3].astype(np.float64) / 4
     v1 = c * 0.6
     ref = np.clip((v1 * (2.51 * v1 + 0.03)) / (v1 * (2.43 * v1 + 0.59) + 0.14), 0, 1) ** (1 / 2.2)
-    assert img.shape == (64, 64, 4) and (img[..., 3] == 255).all()
     assert np.abs(img[..., :3].astype(np.float64) - ref * 255).max() <= 1.0
+    rng = np.random.default_rng(5)
+    sweep = np.concatenate([rng.uniform(0, 40, 64 * 64 * 4 - 16), [0.0, -0.0, -1.0, 1e-30, 1e30, np.inf, -np.inf, np.nan, 0.5, 1.0, 2.0, 3.9999, 4.0, 4.0001, 1e-6, 7.25]]).astype(np.float32).reshape(64, 64, 4)
+    ctx.write_framebuffer(sweep)
+    for frame_num in (1, 4, 7, 512):
+        assert np.array_equal(ctx.resolve_rgba8(frame_num), oracle.resolve_rgba8(sweep, frame_num)), frame_num
 
 
 def test_dragon_class_scene_bit_exact(ctx, pkg, oracle):
