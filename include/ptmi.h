@@ -190,6 +190,11 @@ int ptmi_trace(ptmi_ctx* ctx, size_t n, const float* rays6, uint32_t* rng_inout,
  *     11..13 = components of (x, x*2^-20, x*2^20) / y through the device's vector division */
 int ptmi_math_eval(ptmi_ctx* ctx, int fn, size_t n, const float* x, const float* y, float* out);
 
+/* Test hook: exhaustive check ON THE DEVICE of the unary shortcuts the kernels use instead of the compiler's IEEE expansions
+ * (csrc/ptmi_device.h): which = 0: 1/x, 1: sqrt(x), 2: the three-component reciprocal — each against the IEEE operation over all
+ * 2^32 arguments; 3 / 4: the bare v_rcp_f32 / v_sqrt_f32 instructions (controls that must report mismatches).  *mismatches = number of arguments whose bits differ (NaNs compare equal), *first_bad_bits = the smallest. */
+int ptmi_selftest(ptmi_ctx* ctx, int which, uint64_t* mismatches, uint32_t* first_bad_bits);
+
 /* ---- host-side natives (no GPU needed) -------------------------------------------------------- */
 
 /* Median-split BVH build + pre-order flatten with the reference's exact semantics

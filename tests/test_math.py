@@ -96,3 +96,15 @@ def test_device_vector_division_is_ieee_division(ctx, oracle):
         for fn, scale in ((11, np.float32(1)), (12, np.float32(2.0**-20)), (13, np.float32(2.0**20))):
             want = oracle.math_eval(FN["div"], (a * scale).astype(np.float32), b)
             assert_same_bits(ctx.math_eval(fn, a, b), want, "vector division, component %d" % (fn - 11))
+
+
+@pytest.mark.gpu
+def test_exhaustive_reciprocal_and_sqrt_shortcuts(ctx):
+    """csrc/ptmi_device.h evaluates 1.0f / x as one Newton step on v_rcp_f32 and sqrt(x) as v_sqrt_f32 plus the residual test of its
+    two neighbours (inside guarded ranges; the IEEE expansion outside).  Both are unary, so "the bits of the IEEE operation" is checked
+    by exhaustion: all 2^32 arguments, on the device, against the compiler's correctly rounded expansion (which
+    test_device_math_is_bit_identical_to_host ties to x86).  The bare instructions are the control: they must fail."""
+    for which, name in ((0, "rcp_exact"), (1, "sqrt_exact"), (2, "rcp3_exact")):
+        bad, first = ctx.selftest(which)
+        assert bad == 0, "%s differs from the IEEE operation for %d arguments, first 0x%08x" % (name, bad, first)
+    assert ctx.selftest(3)[0] > 10 ** 8 and ctx.selftest(4)[0] > 10 ** 8  # v_rcp_f32 / v_sqrt_f32 alone are 1-ulp approximations

@@ -48,6 +48,17 @@ def build_lib(force=False, extra_flags=()):
     return LIB
 
 
+def build_variant(name, extra_flags):
+    """A/B builds of the library with extra -D flags: webgpu-path-tracer_amd/variants/libptmi_<name>.so; run with PTMI_LIB=<path>."""
+    vdir = os.path.join(PKG, "variants")
+    os.makedirs(vdir, exist_ok=True)
+    out = os.path.join(vdir, "libptmi_%s.so" % name)
+    srcs = [os.path.join(CSRC, "ptmi.hip"), os.path.join(CSRC, "ptmi_bvh_device.hip"), os.path.join(CSRC, "ptmi_host.cpp")]
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    _run([hipcc] + HIP_FLAGS + list(extra_flags) + ["-o", out] + srcs)
+    return out
+
+
 def build_addon(force=False):
     src = os.path.join(CSRC, "ptmi_napi.c")
     inc = "/usr/include/node"

@@ -1361,6 +1361,30 @@ int ptmi_trace(ptmi_ctx* c, size_t n, const float* rays6, uint32_t* rng_inout, p
   return PTMI_OK;
 }
 
+int ptmi_selftest(ptmi_ctx* c, int which, uint64_t* mismatches, uint32_t* first_bad_bits) {
+  if (!c || !mismatches) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_selftest: null argument");
+  if (which < 0 || which > 4) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_selftest: unknown test id");
+  HIP_TRY(c, hipSetDevice(c->device));
+  DBuf d;
+  HIP_TRY(c, d.ensure(16));
+  int rc = PTMI_OK;
+  do {
+    unsigned long long init[2] = {0ull, 0xffffffffull};
+    hipError_t e = hipMemcpyAsync(d.p, init, 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_selftest, dim3((unsigned)c->num_cus * 16), dim3(256), 0, c->stream, which, d.as<unsigned long long>(), reinterpret_cast<uint32_t*>(d.as<unsigned long long>() + 1));
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(init, d.p, 16, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail(c, PTMI_ERR_DEVICE, std::string("ptmi_selftest: ") + hipGetErrorString(e));
+    *mismatches = init[0];
+    if (first_bad_bits) *first_bad_bits = (uint32_t)init[1];
+  } while (0);
+  d.release();
+  return rc;
+}
+
 int ptmi_math_eval(ptmi_ctx* c, int fn, size_t n, const float* x, const float* y, float* out) {
   if (!c || !x || !out) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_math_eval: null argument");
   if (fn < 0 || fn > 13) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_math_eval: unknown function id");

@@ -62,9 +62,56 @@ DEV f3 operator/(f3 a, float s) {
   return q;
 }
 DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+
+// ---- 1.0f / x and sqrt(x) with the bits of the IEEE operations, in fewer issue cycles -------------------------------------
+// The compiler expands a correctly rounded f32 division into v_div_scale x2, v_rcp, five fma/mul, v_div_fmas, v_div_fixup
+// (11 instructions, ~39 issue cycles, tools/valu_peak.hip), and a square root into 18 instructions of which 7 only serve
+// subnormal, zero and infinite arguments.  For a UNARY function "the same bits" needs no argument: ptmi_selftest runs the
+// candidate against the compiler's expansion over all 2^32 arguments on the device (tests/test_math.py::test_exhaustive_*).
+//   rcp:  inside |x| in [2^-100, 2^100] v_div_scale and v_div_fixup are identities and v_div_fmas is an fma, so the expansion
+//         with numerator 1 is y1 = fma(fma(-x, y0, 1), y0, y0); q1 = fma(fma(-x, y1, 1), y1, y1); q = fma(fma(-x, q1, 1), y1, q1).
+//         PTMI_RCP_STEPS picks how much of it is evaluated (the exhaustive test says what is enough); outside the range, the division.
+//   sqrt: inside x in [2^-90, 2^120] the scaling, un-scaling and the zero/inf pass-through drop out of the expansion.
+#ifndef PTMI_RCP_STEPS
+#define PTMI_RCP_STEPS 1  // exhaustively: one Newton step on v_rcp_f32 already gives the bits of 1.0f / x for every x in the range
+#endif
+__device__ __attribute__((noinline)) float rcp_ieee_slow(float x) { return 1.0f / x; }
+__device__ __attribute__((noinline)) float sqrt_ieee_slow(float x) { return __builtin_sqrtf(x); }
+DEV float rcp_core(float x) {  // valid for |x| in [2^-100, 2^100]
+  const float y0 = __builtin_amdgcn_rcpf(x);
+  const float y1 = __builtin_fmaf(__builtin_fmaf(-x, y0, 1.0f), y0, y0);
+  if (PTMI_RCP_STEPS == 1) return y1;
+  const float q1 = __builtin_fmaf(__builtin_fmaf(-x, y1, 1.0f), y1, y1);
+  if (PTMI_RCP_STEPS == 2) return q1;
+  return __builtin_fmaf(__builtin_fmaf(-x, q1, 1.0f), y1, q1);
+}
+DEV bool rcp_in_range(uint32_t bits) { return ((bits & 0x7fffffffu) - (27u << 23)) < (200u << 23); }  // biased exponent in [27, 227)
+DEV float rcp_exact(float x) {
+  float r = rcp_core(x);
+  if (!rcp_in_range(__float_as_uint(x))) r = rcp_ieee_slow(x);
+  return r;
+}
+// (1/x, 1/y, 1/z) with one range test for the three
+DEV f3 rcp3_exact(f3 a) {
+  f3 r = mk3(rcp_core(a.x), rcp_core(a.y), rcp_core(a.z));
+  const uint32_t lo = 27u << 23;
+  const uint32_t ex = (__float_as_uint(a.x) & 0x7fffffffu) - lo, ey = (__float_as_uint(a.y) & 0x7fffffffu) - lo, ez = (__float_as_uint(a.z) & 0x7fffffffu) - lo;
+  if (max(ex, max(ey, ez)) >= (200u << 23)) r = mk3(rcp_ieee_slow(a.x), rcp_ieee_slow(a.y), rcp_ieee_slow(a.z));
+  return r;
+}
+DEV float sqrt_exact(float x) {
+  // the compiler's sequence without its scaling: s = v_sqrt(x) is within 1 ulp; its neighbours are tried against the exact residuals
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float dn = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+  const float rd = __builtin_fmaf(-dn, s, x), ru = __builtin_fmaf(-up, s, x);
+  float r = (rd <= 0.0f) ? dn : s;
+  r = (ru > 0.0f) ? up : r;
+  if ((__float_as_uint(x) - (37u << 23)) >= (210u << 23)) r = sqrt_ieee_slow(x);  // x < 2^-90 (incl. 0, negative: sign bit set) or >= 2^120 (incl. inf, NaN)
+  return r;
+}
 DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 DEV f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-DEV float len3(f3 a) { return ptm_sqrt(dot3(a, a)); }
+DEV float len3(f3 a) { return sqrt_exact(dot3(a, a)); }
 DEV f3 norm3(f3 a) { return a / len3(a); }
 DEV f3 mix3(f3 a, f3 b, float t) { return a * (1.0f - t) + b * t; }  // stays arithmetic (Q12)
 DEV f3 reflect3(f3 e1, f3 e2) { return e1 - (2.0f * dot3(e2, e1)) * e2; }
@@ -72,7 +119,7 @@ DEV f3 refract3(f3 e1, f3 e2, float e3) {
   float d = dot3(e2, e1);
   float k = 1.0f - e3 * e3 * (1.0f - d * d);
   if (k < 0.0f) return mk3(0, 0, 0);
-  return e3 * e1 - (e3 * d + ptm_sqrt(k)) * e2;
+  return e3 * e1 - (e3 * d + sqrt_exact(k)) * e2;
 }
 
 // column-major mat4 (4 float4 columns) times (v, w): ((c0*x + c1*y) + c2*z) + c3*w
@@ -221,7 +268,7 @@ DEV void camera_ray(const RenderConst& rc, uint32_t pix, int k, uint32_t& rng, f
   float dy = ((m[1] * a + m[5] * b) + m[9] * nf) + m[13] * 0.0f;
   float dz = ((m[2] * a + m[6] * b) + m[10] * nf) + m[14] * 0.0f;
   float dw = ((m[3] * a + m[7] * b) + m[11] * nf) + m[15] * 0.0f;
-  float len = ptm_sqrt(((dx * dx + dy * dy) + dz * dz) + dw * dw);  // normalize() of the vec4, then .xyz
+  float len = sqrt_exact(((dx * dx + dy * dy) + dz * dz) + dw * dw);  // normalize() of the vec4, then .xyz
   d = mk3(dx, dy, dz) / len;
   // cam_origin = (view * (0,0,0,1)).xyz  (main.wgsl:8)
   o = mk3(((m[0] * 0.0f + m[4] * 0.0f) + m[8] * 0.0f) + m[12] * 1.0f, ((m[1] * 0.0f + m[5] * 0.0f) + m[9] * 0.0f) + m[13] * 1.0f,
@@ -264,7 +311,7 @@ DEV bool sphere_root(f3 center, float r, float tmin, float tmax, f3 o, f3 d, flo
   float c = dot3(oc, oc) - r * r;
   float disc = half_b * half_b - a * c;
   if (disc < 0) return false;
-  float sqrtd = ptm_sqrt(disc);
+  float sqrtd = sqrt_exact(disc);
   float root = (-half_b - sqrtd) / a;
   if (root <= tmin || root >= tmax) {
     root = (-half_b + sqrtd) / a;
@@ -365,7 +412,7 @@ DEV void prims_for_ray(const DevScene& S, f3 o, f3 d, uint32_t& rng, float2& tp,
   bool to_bvh = false;
   if (S.n_nodes > 0) {
     if (COUNT) cn.node_visits++;
-    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const f3 inv = rcp3_exact(d);  // 1 / ray.dir (hitRay.wgsl:46)
     to_bvh = hit_aabb(S.root_lo, S.root_hi, c.t, o, inv);
   }
   tp = make_float2(c.t, __uint_as_float(c.prim));
@@ -400,7 +447,7 @@ DEV void hit_triangle(const DevScene& S, int k, f3 o, f3 d, ObjRay& orr, Closest
   if (ptm_abs(det) < kTmin) return;
   f3 ao = orr.o - A;
   f3 dao = cross3(ao, orr.d);
-  float invDet = 1.0f / det;
+  float invDet = rcp_exact(det);
   float dst = dot3(ao, N) * invDet;
   float u = dot3(AC, dao) * invDet;
   float v = -dot3(AB, dao) * invDet;
@@ -502,7 +549,7 @@ DEV void tri_record_test(const DevScene& S, int k, float4 t0, float4 t1, float4 
   if (ptm_abs(det) < kTmin) return;
   f3 ao = t.orr.o - A;
   f3 dao = cross3(ao, t.orr.d);
-  float invDet = 1.0f / det;
+  float invDet = rcp_exact(det);
   float dst = dot3(ao, N) * invDet;
   float u = dot3(AC, dao) * invDet;
   float v = -dot3(AB, dao) * invDet;
@@ -660,8 +707,8 @@ DEV f3 cosine_sampling_wrt_Z(uint32_t& rng) {  // :35-45
   float r1 = rand2D(rng);
   float r2 = rand2D(rng);
   float phi = kTwoPi * r1;
-  float sr = ptm_sqrt(r2);
-  return mk3(ptm_cos(phi) * sr, ptm_sin(phi) * sr, ptm_sqrt(1.0f - r2));
+  float sr = sqrt_exact(r2);
+  return mk3(ptm_cos(phi) * sr, ptm_sin(phi) * sr, sqrt_exact(1.0f - r2));
 }
 DEV float reflectance(float cosine, float ref_idx) {  // :1-5
   float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
@@ -750,10 +797,10 @@ DEV f3 material_scatter(int bin, const Material& m, const HitGeom& g, f3 din, ui
     return norm3(reflected + m.roughness * uniform_random_in_unit_sphere(rng));
   } else if (bin == BIN_GLASS) {
     float ir = m.eta;
-    if (g.front) ir = (1.0f / ir);
+    if (g.front) ir = rcp_exact(ir);
     f3 ud = norm3(din);
     float cos_theta = ptm_min(dot3(-ud, g.n), 1.0f);
-    float sin_theta = ptm_sqrt(1.0f - cos_theta * cos_theta);
+    float sin_theta = sqrt_exact(1.0f - cos_theta * cos_theta);
     f3 dir;
     if (ir * sin_theta > 1.0f || reflectance(cos_theta, ir) > rand2D(rng)) {
       dir = reflect3(ud, g.n);
@@ -764,7 +811,7 @@ DEV f3 material_scatter(int bin, const Material& m, const HitGeom& g, f3 din, ui
   } else if (bin == BIN_ISOTROPIC) {
     float gg = m.specularStrength;
     float cos_hg = (1.0f + gg * gg - ptm_pow(((1.0f - gg * gg) / (1.0f - gg + 2.0f * gg * rand2D(rng))), 2.0f)) / (2.0f * gg);
-    float sin_hg = ptm_sqrt(1.0f - cos_hg * cos_hg);
+    float sin_hg = sqrt_exact(1.0f - cos_hg * cos_hg);
     float phi = kTwoPi * rand2D(rng);
     f3 hg = mk3(sin_hg * ptm_cos(phi), sin_hg * ptm_sin(phi), cos_hg);
     Onb b = onb_build_from_w(din);

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
           const uint32_t hmat = P.hin.mat[myslot] & HITMAT_WORD;
           t.o = mk3(r0);
           t.d = mk3(r1);
-          t.inv = mk3(1.0f / t.d.x, 1.0f / t.d.y, 1.0f / t.d.z);
+          t.inv = rcp3_exact(t.d);
           t.negmask = (t.d.x < 0 ? 1u : 0u) | (t.d.y < 0 ? 2u : 0u) | (t.d.z < 0 ? 4u : 0u);
           t.c.t = h.x, t.c.u = 0.0f, t.c.v = 0.0f, t.c.prim = __float_as_uint(h.y);
           t.c.mat = (hmat != HITMAT_MISS) ? (int)hmat : 0;
@@ -381,7 +381,7 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
         if (rand2D(rng) > p) {
           sample_done = true;
         } else {
-          T = T * (1.0f / p);
+          T = T * rcp_exact(p);
         }
       }
       if (!sample_done) {
@@ -432,7 +432,10 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
   return false;
 }
 
-constexpr int kSChunk = 512;  // slots a k_shade block sorts, shades and compacts at a time
+#ifndef PTMI_SCHUNK
+#define PTMI_SCHUNK 512
+#endif
+constexpr int kSChunk = PTMI_SCHUNK;  // slots a k_shade block sorts, shades and compacts at a time
 
 // ray_color's loop body for one step, 512 slots at a time per block:
 //   1  (SORT) LDS counting sort of the chunk by the shade bin in each slot's material word (ballot ranks), so that
@@ -720,6 +723,38 @@ __global__ void k_math_eval(int fn, size_t n, const float* __restrict__ x, const
     case 13: r = (mk3(a, a * 9.5367431640625e-07f, a * 1048576.0f) / b).z; break;
   }
   out[i] = r;
+}
+
+// Exhaustive self-tests of the unary shortcuts (ptmi_selftest): every one of the 2^32 f32 arguments, candidate against the
+// compiler's IEEE expansion; NaN results count as equal among themselves.  which: 0 rcp_exact, 1 sqrt_exact, 3 / 4 the bare v_rcp_f32 / v_sqrt_f32 (controls: these must fail), 2 rcp3_exact
+// (the argument in turn in each of the three slots, next to two in-range companions, and all three slots equal).
+__global__ __launch_bounds__(256) void k_selftest(int which, unsigned long long* __restrict__ bad, uint32_t* __restrict__ first_bad) {
+  unsigned long long mine = 0;
+  uint32_t first = 0xffffffffu;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < (1ull << 32); i += (uint64_t)gridDim.x * 256) {
+    const uint32_t u = (uint32_t)i;
+    const float x = __uint_as_float(u);
+    bool ok = true;
+    auto same = [](float a, float b) { return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b); };
+    if (which == 0) ok = same(rcp_exact(x), rcp_ieee_slow(x));
+    else if (which == 1) ok = same(sqrt_exact(x), sqrt_ieee_slow(x));
+    else if (which == 3) ok = same(__builtin_amdgcn_rcpf(x), rcp_ieee_slow(x));   // the harness itself: the raw 1-ulp instructions must NOT pass
+    else if (which == 4) ok = same(__builtin_amdgcn_sqrtf(x), sqrt_ieee_slow(x));
+    else {
+      const float want = rcp_ieee_slow(x);
+      const f3 a = rcp3_exact(mk3(x, 3.0f, -0.7f)), b = rcp3_exact(mk3(1.5f, x, 1e-3f)), c = rcp3_exact(mk3(-2.0f, 1e6f, x)), d = rcp3_exact(mk3(x, x, x));
+      ok = same(a.x, want) && same(b.y, want) && same(c.z, want) && same(d.x, want) && same(d.y, want) && same(d.z, want) && a.y == 1.0f / 3.0f && a.z == 1.0f / -0.7f &&
+           b.x == 1.0f / 1.5f && b.z == 1.0f / 1e-3f && c.x == -0.5f && c.y == 1.0f / 1e6f;
+    }
+    if (!ok) {
+      mine++;
+      first = min(first, u);
+    }
+  }
+  if (mine) {
+    atomicAdd(bad, mine);
+    atomicMin(first_bad, first);
+  }
 }
 
 // shaders/fragment.js:22-36 + shaders/common.wgsl:273-282: colour = fb/frameNum -> ACES approx -> gamma

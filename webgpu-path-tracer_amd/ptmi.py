@@ -17,7 +17,7 @@ SYMBOLS = [
     "ptmi_set_params", "ptmi_get_params", "ptmi_upload", "ptmi_resize", "ptmi_clear_framebuffer", "ptmi_set_shard",
     "ptmi_render_frame", "ptmi_render", "ptmi_synchronize", "ptmi_prepare", "ptmi_read_framebuffer", "ptmi_write_framebuffer",
     "ptmi_framebuffer_device_ptr", "ptmi_bind_framebuffer", "ptmi_stream", "ptmi_resolve_rgba8", "ptmi_set_counters",
-    "ptmi_set_timing", "ptmi_get_stats", "ptmi_reset_stats", "ptmi_trace", "ptmi_math_eval", "ptmi_build_bvh",
+    "ptmi_set_timing", "ptmi_get_stats", "ptmi_reset_stats", "ptmi_trace", "ptmi_math_eval", "ptmi_selftest", "ptmi_build_bvh",
     "ptmi_build_bvh_sah", "ptmi_build_bvh_device", "ptmi_obj_parse", "ptmi_free",
 ]
 
@@ -64,9 +64,10 @@ def load_library(build=False):
         return _lib
     if build:
         _build.build_lib()
-    if not os.path.exists(_build.LIB):
+    path = os.environ.get("PTMI_LIB") or _build.LIB  # PTMI_LIB: an A/B build (_build.build_variant), as for the N-API addon
+    if not os.path.exists(path):
         raise OSError("libptmi.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc)")
-    L = ctypes.CDLL(_build.LIB)
+    L = ctypes.CDLL(path)
     vp, i32, u32, sz, fp = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_size_t, ctypes.c_void_p
     L.ptmi_version.restype = i32
     L.ptmi_status_string.restype = ctypes.c_char_p
@@ -101,6 +102,7 @@ def load_library(build=False):
     L.ptmi_reset_stats.argtypes = [vp]
     L.ptmi_trace.argtypes = [vp, sz, fp, fp, fp]
     L.ptmi_math_eval.argtypes = [vp, i32, sz, fp, fp, fp]
+    L.ptmi_selftest.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
     L.ptmi_build_bvh.argtypes = [sz, fp, fp, i32, fp, fp]
     L.ptmi_build_bvh_sah.argtypes = [sz, fp, fp, i32, fp, fp, ctypes.POINTER(sz)]
     L.ptmi_build_bvh_device.argtypes = [vp, sz, fp, fp, i32, fp, fp]
@@ -318,6 +320,12 @@ class Context:
         g = None if rng is None else np.ascontiguousarray(rng, np.uint32).copy()
         self._ck(self.lib.ptmi_trace(self.h, n, _ptr(r), None if g is None else _ptr(g), _ptr(out)))
         return out, g
+
+    def selftest(self, which):
+        """Exhaustive device-side check of a unary shortcut against the IEEE operation: (mismatches, first bad argument bits)."""
+        n, first = ctypes.c_uint64(), ctypes.c_uint32()
+        self._ck(self.lib.ptmi_selftest(self.h, which, ctypes.byref(n), ctypes.byref(first)))
+        return n.value, first.value
 
     def math_eval(self, fn, x, y=None):
         x = np.ascontiguousarray(x, np.float32)
