@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 def test_bench_two_ranks_on_one_gpu():
-    common = ["--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--width", "320", "--height", "180", "--spp", "4"]
+    common = ["--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--pmc", "off", "--extra-configs", "off", "--width", "320", "--height", "180", "--spp", "4"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     one = subprocess.run([sys.executable, "bench.py"] + common, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
@@ -28,3 +28,9 @@ def test_bench_two_ranks_on_one_gpu():
     # weak scaling: 2x the frames over the same pixels; frames 1..8 instead of 1..4, so about twice the rays
     assert 1.8 < b["config"]["rays_per_step"] / a["config"]["rays_per_step"] < 2.2
     assert "roofline" in b and "pixel tiles x2" in b["config"]["parallelism"]
+    # strong scaling: the same 4 frames split by pixel tiles, so exactly the rays of the one-rank run
+    three = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29534",
+                            "bench.py", "--gpus", "2", "--rehearse-gloo", "--scaling", "strong"] + common, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert three.returncode == 0, three.stderr[-2000:]
+    c = json.loads([l for l in three.stdout.strip().splitlines() if l.startswith("{")][0])
+    assert c["scaling"] == "strong" and c["config"]["rays_per_step"] == a["config"]["rays_per_step"]

@@ -156,6 +156,13 @@ def test_upload_validation_errors(ctx, pkg):
         with pytest.raises(pkg.PtmiError) as e:
             ctx.render(cornell_view(pkg), 1, 1)
         assert e.value.status == -5, (row, col, val)
+    tri = b["triangles"].copy()
+    for val in (7.0, -1.0, np.nan, 3.0e9):  # mesh_id of triangle 5 (checked by the digest kernel on the device)
+        tri[24 * 5 + 23] = val
+        ctx.upload_scene({**b, "triangles": tri})
+        with pytest.raises(pkg.PtmiError) as e:
+            ctx.render(cornell_view(pkg), 1, 1)
+        assert e.value.status == -5 and "triangle 5" in str(e.value), val
     ctx.upload_scene(b)
     ctx.render(cornell_view(pkg), 1, 1)  # recovers
     ctx.synchronize()

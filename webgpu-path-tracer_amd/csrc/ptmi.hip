@@ -264,29 +264,9 @@ int prepare_scene(ptmi_ctx* c) {
     use_class(me[3]);
   }
   c->material_classes = __builtin_popcount(classes);
-  // pretri digest: same f32 operations the shader performs per test (common.wgsl:199-201)
-  std::vector<float> pretri(16 * (size_t)n_tri);
-  for (int i = 0; i < n_tri; i++) {
-    const float* t = &c->h_tris[24 * (size_t)i];
-    int mesh;
-    if (!id_from_float(t[23], n_mesh, &mesh)) {
-      snprintf(msg, sizeof msg, "triangle %d: mesh_id out of range [0,%d)", i, n_mesh);
-      return fail(c, PTMI_ERR_BAD_SCENE, msg);
-    }
-    float* o = &pretri[16 * (size_t)i];
-    float ABx = t[4] - t[0], ABy = t[5] - t[1], ABz = t[6] - t[2];
-    float ACx = t[8] - t[0], ACy = t[9] - t[1], ACz = t[10] - t[2];
-    o[0] = t[0], o[1] = t[1], o[2] = t[2];
-    memcpy(&o[3], &mesh, 4);
-    o[4] = ABx, o[5] = ABy, o[6] = ABz;
-    o[8] = ACx, o[9] = ACy, o[10] = ACz;
-    memcpy(&o[7], &mat_word[c->h_meshes[4 * (size_t)mesh + 3]], 4);
-    memcpy(&o[11], &c->h_meshes[4 * (size_t)mesh + 2], 4);
-    o[12] = ABy * ACz - ABz * ACy;
-    o[13] = ABz * ACx - ABx * ACz;
-    o[14] = ABx * ACy - ABy * ACx;
-    o[15] = 0.0f;
-  }
+  // (the pretri digest is computed on the device from the uploaded triangles: k_pretri_digest, below)
+  std::vector<int32_t> mesh_matword((size_t)n_mesh);
+  for (int i = 0; i < n_mesh; i++) mesh_matword[i] = mat_word[c->h_meshes[4 * (size_t)i + 3]];
   // Tree check + pair64 digest.  Children always have larger indices than their parent (left = i+1,
   // right > i+1), so a walk from the root terminates; "every node reached at most once" excludes
   // shared subtrees (which could make a traversal exponentially long).
@@ -385,8 +365,25 @@ int prepare_scene(ptmi_ctx* c) {
     HIP_TRY(c, hipGetLastError());
   }
   HIP_TRY(c, up(c->d_tris, c->h_tris.data(), c->h_tris.size() * 4));
-  HIP_TRY(c, up(c->d_pretri, pretri.data(), pretri.size() * 4));
   HIP_TRY(c, up(c->d_meshes, c->h_meshes.data(), c->h_meshes.size() * 4));
+  HIP_TRY(c, c->d_pretri.ensure(std::max<size_t>((size_t)n_tri * 64, 16)));
+  if (n_tri > 0) {
+    // scratch: [first bad triangle index][mesh material words...]
+    HIP_TRY(c, c->d_scratch.ensure(16 + (size_t)n_mesh * 4));
+    const uint32_t none = 0xffffffffu;
+    HIP_TRY(c, hipMemcpyAsync(c->d_scratch.p, &none, 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync((char*)c->d_scratch.p + 16, mesh_matword.data(), (size_t)n_mesh * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_pretri_digest, dim3((unsigned)((n_tri + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->d_tris.as<float4>(), n_tri, c->d_meshes.as<int4>(), n_mesh,
+                       reinterpret_cast<const int*>((char*)c->d_scratch.p + 16), c->d_pretri.as<float4>(), c->d_scratch.as<uint32_t>());
+    HIP_TRY(c, hipGetLastError());
+    uint32_t bad = none;
+    HIP_TRY(c, hipMemcpyAsync(&bad, c->d_scratch.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (bad != none) {
+      snprintf(msg, sizeof msg, "triangle %u: mesh_id out of range [0,%d)", bad, n_mesh);
+      return fail(c, PTMI_ERR_BAD_SCENE, msg);
+    }
+  }
   HIP_TRY(c, up(c->d_xforms, c->h_xforms.data(), c->h_xforms.size() * 4));
   HIP_TRY(c, up(c->d_mats, c->h_mats.data(), c->h_mats.size() * 4));
   HIP_TRY(c, up(c->d_pairs, pairs.data(), pairs.size() * 4));

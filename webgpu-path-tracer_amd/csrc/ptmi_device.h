@@ -75,6 +75,8 @@ DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 #ifndef PTMI_RCP_STEPS
 #define PTMI_RCP_STEPS 1  // exhaustively: one Newton step on v_rcp_f32 already gives the bits of 1.0f / x for every x in the range
 #endif
+// The out-of-range path: a call where registers are plentiful and code size matters (k_shade: inlining it cost configs[1] 4 %),
+// inline inside k_bvh, whose triangle test pays for the registers saved around a call (configs[3]: 4 %).
 __device__ __attribute__((noinline)) float rcp_ieee_slow(float x) { return 1.0f / x; }
 __device__ __attribute__((noinline)) float sqrt_ieee_slow(float x) { return __builtin_sqrtf(x); }
 DEV float rcp_core(float x) {  // valid for |x| in [2^-100, 2^100]
@@ -91,12 +93,24 @@ DEV float rcp_exact(float x) {
   if (!rcp_in_range(__float_as_uint(x))) r = rcp_ieee_slow(x);
   return r;
 }
+DEV float rcp_exact_il(float x) {  // the same with the fallback inline (k_bvh)
+  float r = rcp_core(x);
+  if (!rcp_in_range(__float_as_uint(x))) r = 1.0f / x;
+  return r;
+}
 // (1/x, 1/y, 1/z) with one range test for the three
 DEV f3 rcp3_exact(f3 a) {
   f3 r = mk3(rcp_core(a.x), rcp_core(a.y), rcp_core(a.z));
   const uint32_t lo = 27u << 23;
   const uint32_t ex = (__float_as_uint(a.x) & 0x7fffffffu) - lo, ey = (__float_as_uint(a.y) & 0x7fffffffu) - lo, ez = (__float_as_uint(a.z) & 0x7fffffffu) - lo;
   if (max(ex, max(ey, ez)) >= (200u << 23)) r = mk3(rcp_ieee_slow(a.x), rcp_ieee_slow(a.y), rcp_ieee_slow(a.z));
+  return r;
+}
+DEV f3 rcp3_exact_il(f3 a) {
+  f3 r = mk3(rcp_core(a.x), rcp_core(a.y), rcp_core(a.z));
+  const uint32_t lo = 27u << 23;
+  const uint32_t ex = (__float_as_uint(a.x) & 0x7fffffffu) - lo, ey = (__float_as_uint(a.y) & 0x7fffffffu) - lo, ez = (__float_as_uint(a.z) & 0x7fffffffu) - lo;
+  if (max(ex, max(ey, ez)) >= (200u << 23)) r = mk3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z);
   return r;
 }
 DEV float sqrt_exact(float x) {
@@ -447,7 +461,7 @@ DEV void hit_triangle(const DevScene& S, int k, f3 o, f3 d, ObjRay& orr, Closest
   if (ptm_abs(det) < kTmin) return;
   f3 ao = orr.o - A;
   f3 dao = cross3(ao, orr.d);
-  float invDet = rcp_exact(det);
+  float invDet = rcp_exact_il(det);
   float dst = dot3(ao, N) * invDet;
   float u = dot3(AC, dao) * invDet;
   float v = -dot3(AB, dao) * invDet;
@@ -549,7 +563,7 @@ DEV void tri_record_test(const DevScene& S, int k, float4 t0, float4 t1, float4 
   if (ptm_abs(det) < kTmin) return;
   f3 ao = t.orr.o - A;
   f3 dao = cross3(ao, t.orr.d);
-  float invDet = rcp_exact(det);
+  float invDet = rcp_exact_il(det);
   float dst = dot3(ao, N) * invDet;
   float u = dot3(AC, dao) * invDet;
   float v = -dot3(AB, dao) * invDet;

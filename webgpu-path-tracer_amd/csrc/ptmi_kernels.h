@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
           const uint32_t hmat = P.hin.mat[myslot] & HITMAT_WORD;
           t.o = mk3(r0);
           t.d = mk3(r1);
-          t.inv = rcp3_exact(t.d);
+          t.inv = rcp3_exact_il(t.d);
           t.negmask = (t.d.x < 0 ? 1u : 0u) | (t.d.y < 0 ? 2u : 0u) | (t.d.z < 0 ? 4u : 0u);
           t.c.t = h.x, t.c.u = 0.0f, t.c.v = 0.0f, t.c.prim = __float_as_uint(h.y);
           t.c.mat = (hmat != HITMAT_MISS) ? (int)hmat : 0;
@@ -662,6 +662,31 @@ __global__ void k_quad_digest(const float4* __restrict__ quads, int n, float4* _
   unit_n[i] = make_float4(u.x, u.y, u.z, 0.0f);
 }
 
+// Upload-time digest: pretri (DevScene) from the raw triangles, one thread per triangle — the subtractions and the cross product
+// the shader performs per test (common.wgsl:199-201), the same f32 operations in the same order.  A mesh id outside [0, n_meshes)
+// is reported through `first_bad` (smallest offending triangle index) instead of being dereferenced.
+__global__ __launch_bounds__(kBlock) void k_pretri_digest(const float4* __restrict__ tris, int n_tris, const int4* __restrict__ meshes, int n_meshes,
+                                                          const int* __restrict__ mesh_matword, float4* __restrict__ pretri, uint32_t* __restrict__ first_bad) {
+  const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+  if (i >= n_tris) return;
+  const float4* t = tris + 6 * (size_t)i;
+  const float4 A = t[0], B = t[1], C = t[2];
+  const float mf = t[5].w;  // mesh_id travels as a float (lib/primitives/triangle.js:42-52)
+  if (!(mf >= 0.0f) || !(mf < 2147483000.0f) || (int)mf >= n_meshes) {
+    atomicMin(first_bad, (uint32_t)i);
+    return;
+  }
+  const int mesh = (int)mf;
+  const int4 me = meshes[mesh];
+  const float ABx = B.x - A.x, ABy = B.y - A.y, ABz = B.z - A.z;
+  const float ACx = C.x - A.x, ACy = C.y - A.y, ACz = C.z - A.z;
+  float4* o = pretri + 4 * (size_t)i;
+  o[0] = make_float4(A.x, A.y, A.z, __int_as_float(mesh));
+  o[1] = make_float4(ABx, ABy, ABz, __int_as_float(mesh_matword[mesh]));
+  o[2] = make_float4(ACx, ACy, ACz, __int_as_float(me.z));  // the mesh's global_id = its transform index
+  o[3] = make_float4(ABy * ACz - ABz * ACy, ABz * ACx - ABx * ACz, ABx * ACy - ABy * ACx, 0.0f);
+}
+
 // ---- test hooks ------------------------------------------------------------------------------------
 struct HitOut {
   int32_t hit;
@@ -736,13 +761,13 @@ __global__ __launch_bounds__(256) void k_selftest(int which, unsigned long long*
     const float x = __uint_as_float(u);
     bool ok = true;
     auto same = [](float a, float b) { return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b); };
-    if (which == 0) ok = same(rcp_exact(x), rcp_ieee_slow(x));
+    if (which == 0) ok = same(rcp_exact(x), rcp_ieee_slow(x)) && same(rcp_exact_il(x), rcp_ieee_slow(x));
     else if (which == 1) ok = same(sqrt_exact(x), sqrt_ieee_slow(x));
     else if (which == 3) ok = same(__builtin_amdgcn_rcpf(x), rcp_ieee_slow(x));   // the harness itself: the raw 1-ulp instructions must NOT pass
     else if (which == 4) ok = same(__builtin_amdgcn_sqrtf(x), sqrt_ieee_slow(x));
     else {
       const float want = rcp_ieee_slow(x);
-      const f3 a = rcp3_exact(mk3(x, 3.0f, -0.7f)), b = rcp3_exact(mk3(1.5f, x, 1e-3f)), c = rcp3_exact(mk3(-2.0f, 1e6f, x)), d = rcp3_exact(mk3(x, x, x));
+      const f3 a = rcp3_exact(mk3(x, 3.0f, -0.7f)), b = rcp3_exact_il(mk3(1.5f, x, 1e-3f)), c = rcp3_exact(mk3(-2.0f, 1e6f, x)), d = rcp3_exact_il(mk3(x, x, x));
       ok = same(a.x, want) && same(b.y, want) && same(c.z, want) && same(d.x, want) && same(d.y, want) && same(d.z, want) && a.y == 1.0f / 3.0f && a.z == 1.0f / -0.7f &&
            b.x == 1.0f / 1.5f && b.z == 1.0f / 1e-3f && c.x == -0.5f && c.y == 1.0f / 1e6f;
     }

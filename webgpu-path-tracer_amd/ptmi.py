@@ -102,7 +102,8 @@ def load_library(build=False):
     L.ptmi_reset_stats.argtypes = [vp]
     L.ptmi_trace.argtypes = [vp, sz, fp, fp, fp]
     L.ptmi_math_eval.argtypes = [vp, i32, sz, fp, fp, fp]
-    L.ptmi_selftest.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
+    if hasattr(L, "ptmi_selftest"):  # (an older A/B build loaded through PTMI_LIB may lack the newest test hooks)
+        L.ptmi_selftest.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
     L.ptmi_build_bvh.argtypes = [sz, fp, fp, i32, fp, fp]
     L.ptmi_build_bvh_sah.argtypes = [sz, fp, fp, i32, fp, fp, ctypes.POINTER(sz)]
     L.ptmi_build_bvh_device.argtypes = [vp, sz, fp, fp, i32, fp, fp]
