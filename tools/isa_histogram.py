@@ -55,29 +55,29 @@ def classify(op):
 
 
 def issue_weights():
-    """Cycles per wave-instruction per SIMD at 5 waves/SIMD, from the microbenchmark (profiles/valu_peak.json)."""
-    w = collections.defaultdict(lambda: 2.0)
+    """Issue cycles per wave-instruction per SIMD (throughput at 8 waves/SIMD, wall clock) from the microbenchmark
+    (tools/valu_peak.hip -> profiles/valu_peak.json), rounded to the hardware's classes 2 / 4 / 8 / 16."""
+    w = collections.defaultdict(lambda: 4.0)
     p = os.path.join(ROOT, "profiles", "valu_peak.json")
     if not os.path.exists(p):
         return w, None
     d = json.load(open(p))
-    cyc = {}
-    for c in d["cases"]:
-        if c["waves_per_simd"] == 5:
-            cyc[c["op"]] = c["cycles_per_wave_instr_per_simd_in_kernel"]
-    g = lambda k, dflt: cyc.get(k, dflt)
+    cyc = {c["op"]: c["cycles_per_wave_instr_per_simd_wall"] for c in d["cases"] if c["waves_per_simd"] == 8}
+
+    def g(op, dflt):
+        v = cyc.get(op, dflt)
+        return min((2.0, 4.0, 8.0, 16.0), key=lambda k: abs(k - v))
+
     w.update({
-        "f32_fma": g("v_fma_f32", 2), "f32_mul_add": g("v_mul_f32", 2), "f32_minmax": g("v_min_f32", 2), "cmp": g("v_cmp_class_f32", 2),
-        "cndmask_mov": g("v_cndmask_b32", 2), "int": g("v_mad_u32_u24", 2), "f32_pk": g("v_pk_fma_f32", 4), "f32_trans": g("v_sqrt_f32", 8),
-        "f32_div_helpers": (g("v_div_scale_f32", 2) + g("v_div_fixup_f32", 2)) / 2, "f64_arith": g("v_fma_f64", 4), "f64_trans": g("v_rcp_f64", 16),
-        "cvt": (g("v_cvt_f64_f32", 2) + g("v_cvt_f32_f64", 2)) / 2, "valu_other": 2.0,
+        "f32_fma": g("v_fma_f32", 2), "f32_mul_add": g("v_mul_f32", 2), "f32_minmax": g("v_min_f32", 4), "cmp": g("v_cmp_gt_f32", 4),
+        "cndmask_mov": g("v_mov_b32", 2), "int": (g("v_add_u32", 2) + g("v_lshlrev_b32", 4)) / 2, "f32_pk": g("v_pk_fma_f32", 4), "f32_trans": g("v_sqrt_f32", 8),
+        "f32_div_helpers": g("v_div_scale_f32", 4), "f64_arith": g("v_fma_f64", 4), "f64_trans": g("v_rcp_f64", 16), "cvt": g("v_cvt_f64_f32", 4), "valu_other": 4.0,
     })
     return w, p
 
 
-def assembly():
-    src = os.path.join(ROOT, "webgpu-path-tracer_amd", "csrc", "ptmi.hip")
-    out = "/tmp/ptmi_isa.s"
+def assembly(src=None, out="/tmp/ptmi_isa.s"):
+    src = src or os.path.join(ROOT, "webgpu-path-tracer_amd", "csrc", "ptmi.hip")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-command-line-argument"]
     subprocess.run(["hipcc"] + flags + ["--cuda-device-only", "-S", "-o", out, src], check=True)
     return open(out).read().splitlines()
@@ -102,12 +102,43 @@ def kernels(lines):
     return out
 
 
+def count(lines, b, e):
+    total = collections.Counter()
+    for l in lines[b + 1:e]:
+        t = l.strip()
+        m = re.match(r"^([a-z][a-z0-9_]+)(\s|$)", t)
+        if not m or t.startswith("."):
+            continue
+        total[classify(re.sub(r"_(e32|e64|dpp|sdwa)$", "", m.group(1)))] += 1
+    return total
+
+
+def pieces(a):
+    lines = assembly(os.path.join(ROOT, "tools", "isa_pieces.hip"), "/tmp/ptmi_pieces.s")
+    w, _ = issue_weights()
+    res = {}
+    for name, (b, e) in kernels(lines).items():
+        if not name.startswith("p_"):
+            continue
+        t = count(lines, b, e)
+        valu = sum(v for k, v in t.items() if k in VALU)
+        cyc = sum(v * w[k] for k, v in t.items() if k in VALU)
+        res[name[2:]] = {"static_valu": valu, "valu_issue_cycles_weighted": cyc, "by_class": dict(t.most_common())}
+        print("%-18s VALU %4d  issue cycles %5.0f  | %s" % (name[2:], valu, cyc, ", ".join("%s %d" % kv for kv in t.most_common(6))))
+    if a.json:
+        json.dump({"_note": "static counts of stand-alone kernels wrapping one building block each (tools/isa_pieces.hip; includes ~6 instructions of load/store scaffolding); "
+                            "loops (the quad loop of prims) are counted once; weights as in r02_isa_histogram.json", "pieces": res}, open(a.json, "w"), indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("kernel", help="substring of the demangled kernel name, e.g. 'k_shade<false, false, false>'")
+    ap.add_argument("kernel", nargs="?", default="", help="substring of the demangled kernel name, e.g. 'k_shade<false, false, false>'")
+    ap.add_argument("--pieces", action="store_true", help="instead: the building blocks of tools/isa_pieces.hip (norm3, div3, sqrt, rcp, rand, scatter, prims ...), one line each")
     ap.add_argument("--blocks", action="store_true", help="also list the largest basic blocks")
     ap.add_argument("--json", default=None)
     a = ap.parse_args()
+    if a.pieces:
+        return pieces(a)
     lines = assembly()
     ks = kernels(lines)
     want = [s for s in ks if a.kernel.replace(" ", "") in demangle(s.lstrip(".L") if s.startswith(".L_Z") else s).replace(" ", "")]
