@@ -608,11 +608,16 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
     }
     {
       ScopedSpan sp(c, T_SHADE);
-#define PTMI_LAUNCH_SHADE(IS, SO, CN) hipLaunchKernelGGL((k_shade<IS, SO, CN>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, c->d_heads.as<uint32_t>(), tot, s == 0 ? 1 : 0)
-#define PTMI_LAUNCH_SHADE2(IS, SO) \
-  do {                             \
-    if (c->counters) PTMI_LAUNCH_SHADE(IS, SO, true); \
-    else PTMI_LAUNCH_SHADE(IS, SO, false);            \
+#define PTMI_LAUNCH_SHADE(IS, SO, CN, MU) hipLaunchKernelGGL((k_shade<IS, SO, CN, MU>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, c->d_heads.as<uint32_t>(), tot, s == 0 ? 1 : 0)
+#define PTMI_LAUNCH_SHADE2(IS, SO)                          \
+  do {                                                      \
+    if (rc.num_samples > 1) {                               \
+      if (c->counters) PTMI_LAUNCH_SHADE(IS, SO, true, true); \
+      else PTMI_LAUNCH_SHADE(IS, SO, false, true);          \
+    } else {                                                \
+      if (c->counters) PTMI_LAUNCH_SHADE(IS, SO, true, false); \
+      else PTMI_LAUNCH_SHADE(IS, SO, false, false);         \
+    }                                                       \
   } while (0)
       if (p.importance_sampling) {
         if (sort) PTMI_LAUNCH_SHADE2(true, true);

@@ -302,7 +302,10 @@ DEV void acc_store(const Paths& P, uint32_t pid, float4 v) {
   if (P.touched) P.touched[pid] = 1;
 }
 
-template <bool IS>
+// MULTI = NUM_SAMPLES > 1 (the per-pixel sample loop of shootRay.wgsl:5-49 lives in the slot: pixsum, in-slot camera ray); the
+// reference's progressive mode (NUM_SAMPLES = 1) compiles without it, which also frees the scalar registers the view matrix and
+// the image constants would occupy through the whole kernel.
+template <bool IS, bool MULTI>
 DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, const SlotState& st, const QuadL& L, NewState& ns) {
   const uint32_t pid = __float_as_uint(st.q1.w);
   const f3 o = mk3(st.q0), d = mk3(st.q1);
@@ -404,7 +407,7 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
   }
 
   // pathTrace (shootRay.wgsl:5-49): pixColor += ray_color(ray); pixColor /= NUM_SAMPLES
-  if (rc.num_samples == 1) {
+  if (!MULTI) {
     if (drop_acc) {
       f3 fin = (mk3(0, 0, 0) + add) / rc.sample_div;
       acc_store(P, pid, make_float4(fin.x, fin.y, fin.z, __int_as_float(1)));
@@ -414,7 +417,7 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
       acc_store(P, pid, make_float4(fin.x, fin.y, fin.z, __int_as_float(1)));
     }  // else: (0 + acc) / 1 == acc, already in place — or never written, which k_accumulate reads as zero
     return false;
-  }
+  } else {
   float4 A4 = P.acc[pid];
   int sample = __float_as_int(A4.w);
   f3 radiance = drop_acc ? add : (mk3(A4) + add);
@@ -430,6 +433,7 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
   f3 fin = sum / rc.sample_div;
   P.acc[pid] = make_float4(fin.x, fin.y, fin.z, __int_as_float(sample));
   return false;
+  }
 }
 
 #ifndef PTMI_SCHUNK
@@ -446,7 +450,7 @@ constexpr int kSChunk = PTMI_SCHUNK;  // slots a k_shade block sorts, shades and
 //      record go to the block's current OUTPUT REGION of the next queue, coalesced.  A block claims a region with one
 //      global atomic (16 or so per launch), fills it across chunks — an entry that does not fit any more continues in
 //      the next region — and marks what is left at the end as holes.
-template <bool IS, bool SORT, bool COUNT>
+template <bool IS, bool SORT, bool COUNT, bool MULTI>
 __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads,
                                                                   unsigned long long* __restrict__ totals, int first) {
   reset_heads(heads);
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, Re
         ns.bounce = 0, ns.rng = 0, ns.pid = 0;
         if (k < nvalid) {
           const SlotState st = load_slot(P, base + s_sorted[k], first != 0);
-          survive = shade_one<IS>(S, rc, P, st, L, ns);
+          survive = shade_one<IS, MULTI>(S, rc, P, st, L, ns);
         }
         stage(survive, ns);
       }
@@ -559,7 +563,7 @@ __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, Re
         if (j < m) {
           const SlotState st = load_slot(P, base + j, first != 0);
           valid = __float_as_uint(st.q1.w) != PID_HOLE;
-          if (valid) survive = shade_one<IS>(S, rc, P, st, L, ns);
+          if (valid) survive = shade_one<IS, MULTI>(S, rc, P, st, L, ns);
         }
         my_valid += (uint32_t)__popcll(__ballot(valid));
         stage(survive, ns);
