@@ -65,7 +65,8 @@ struct ptmi_ctx {
   int num_cus = 256;
 
   // host copies of the uploaded arrays (reference layouts)
-  std::vector<float> h_spheres, h_quads, h_tris, h_xforms, h_mats, h_bvh;
+  std::vector<float> h_spheres, h_quads, h_xforms, h_mats, h_bvh;
+  size_t n_tris_uploaded = 0;  // the triangles go straight to the device (d_tris): the host never needs their values again
   std::vector<int32_t> h_meshes;
   bool scene_dirty = true;
 
@@ -212,7 +213,7 @@ bool id_from_float(float f, int n, int* out) {  // i32(f32) of an index field, r
 // Validate every index the kernels will dereference and build the digests (see DevScene).
 int prepare_scene(ptmi_ctx* c) {
   if (!c->scene_dirty) return PTMI_OK;
-  const int n_sph = (int)(c->h_spheres.size() / 8), n_quad = (int)(c->h_quads.size() / 20), n_tri = (int)(c->h_tris.size() / 24);
+  const int n_sph = (int)(c->h_spheres.size() / 8), n_quad = (int)(c->h_quads.size() / 20), n_tri = (int)c->n_tris_uploaded;
   const int n_mesh = (int)(c->h_meshes.size() / 4), n_xf = (int)(c->h_xforms.size() / 32), n_mat = (int)(c->h_mats.size() / 16);
   const int n_node = (int)(c->h_bvh.size() / 12);
   char msg[256];
@@ -364,7 +365,6 @@ int prepare_scene(ptmi_ctx* c) {
     hipLaunchKernelGGL(k_quad_digest, dim3((unsigned)((n_quad + 63) / 64)), dim3(64), 0, c->stream, c->d_quads.as<float4>(), n_quad, c->d_quad_unit_n.as<float4>());
     HIP_TRY(c, hipGetLastError());
   }
-  HIP_TRY(c, up(c->d_tris, c->h_tris.data(), c->h_tris.size() * 4));
   HIP_TRY(c, up(c->d_meshes, c->h_meshes.data(), c->h_meshes.size() * 4));
   HIP_TRY(c, c->d_pretri.ensure(std::max<size_t>((size_t)n_tri * 64, 16)));
   if (n_tri > 0) {
@@ -991,7 +991,13 @@ int ptmi_upload(ptmi_ctx* c, int which, const void* data, size_t bytes) {
   switch (which) {
     case PTMI_BUF_SPHERES: c->h_spheres.assign(f, f + bytes / 4); break;
     case PTMI_BUF_QUADS: c->h_quads.assign(f, f + bytes / 4); break;
-    case PTMI_BUF_TRIANGLES: c->h_tris.assign(f, f + bytes / 4); break;
+    case PTMI_BUF_TRIANGLES:  // the largest buffer (84 MB at 871 k triangles): no host copy, one synchronous transfer from the caller's memory
+      HIP_TRY(c, hipSetDevice(c->device));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));  // nothing in flight may still read the old triangles
+      HIP_TRY(c, c->d_tris.ensure(std::max<size_t>(bytes, 16)));
+      if (bytes) HIP_TRY(c, hipMemcpy(c->d_tris.p, data, bytes, hipMemcpyHostToDevice));
+      c->n_tris_uploaded = bytes / 96;
+      break;
     case PTMI_BUF_MESHES: c->h_meshes.assign((const int32_t*)data, (const int32_t*)data + bytes / 4); break;
     case PTMI_BUF_TRANSFORMS: c->h_xforms.assign(f, f + bytes / 4); break;
     case PTMI_BUF_MATERIALS: c->h_mats.assign(f, f + bytes / 4); break;
