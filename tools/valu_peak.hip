@@ -32,10 +32,10 @@
 
 constexpr int kIter = 2048, kPerIter = 64;
 
-enum Op { FMA32, MUL32, MIN32, CNDMASK, MOV, PKFMA32, PKMUL32, SQRT32, RCP32, RSQ32, FMA64, MUL64, ADD64, RCP64, CVT_F64_F32, CVT_F32_F64, CMP_CLASS32, CMP_GT32, DIVSCALE32, DIVFMAS32, DIVFIXUP32, MAD_U32, MUL_LO_U32, ADD_U32, AND_B32, LSHLREV, XOR_B32, ADD_F32, CVT_F32_U32, CNDMASK_SGPR, MAX3, N_OPS };
+enum Op { FMA32, MUL32, MIN32, CNDMASK, MOV, PKFMA32, PKMUL32, SQRT32, RCP32, RSQ32, FMA64, MUL64, ADD64, RCP64, CVT_F64_F32, CVT_F32_F64, CMP_CLASS32, CMP_GT32, DIVSCALE32, DIVFMAS32, DIVFIXUP32, MAD_U32, MUL_LO_U32, ADD_U32, AND_B32, LSHLREV, XOR_B32, ADD_F32, CVT_F32_U32, CNDMASK_SGPR, MAX3, FMA32_HALF, MIN32_HALF, N_OPS };
 const char* kNames[N_OPS] = {"v_fma_f32", "v_mul_f32", "v_min_f32", "v_cndmask_b32", "v_mov_b32", "v_pk_fma_f32", "v_pk_mul_f32", "v_sqrt_f32", "v_rcp_f32", "v_rsq_f32", "v_fma_f64",
                              "v_mul_f64", "v_add_f64", "v_rcp_f64", "v_cvt_f64_f32", "v_cvt_f32_f64", "v_cmp_class_f32", "v_cmp_gt_f32", "v_div_scale_f32", "v_div_fmas_f32", "v_div_fixup_f32",
-                             "v_mad_u32_u24", "v_mul_lo_u32", "v_add_u32", "v_and_b32", "v_lshlrev_b32", "v_xor_b32", "v_add_f32", "v_cvt_f32_u32", "v_cndmask_b32 (sgpr-pair mask)", "v_max3_f32"};
+                             "v_mad_u32_u24", "v_mul_lo_u32", "v_add_u32", "v_and_b32", "v_lshlrev_b32", "v_xor_b32", "v_add_f32", "v_cvt_f32_u32", "v_cndmask_b32 (sgpr-pair mask)", "v_max3_f32", "v_fma_f32, EXEC = lanes 0-31 only", "v_min_f32, EXEC = lanes 0-31 only"};
 
 struct WaveRec {
   unsigned long long cycles, realtime;
@@ -60,15 +60,18 @@ __global__ __launch_bounds__(1024) void k_issue(float* __restrict__ sink, WaveRe
   const unsigned long long lane_mask = __ballot(threadIdx.x & 1);  // a real per-lane mask in an SGPR pair
   __syncthreads();  // all waves of the block start together
   const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  // partial-EXEC cases: does the SIMD skip the 32-lane pass whose lanes are all masked off?
+  const int live = (OP == FMA32_HALF || OP == MIN32_HALF) ? 32 : 64;
+  if ((int)(threadIdx.x & 63) < live)
 #pragma unroll 1
   for (int it = 0; it < kIter; it++) {
 #pragma unroll
     for (int rep = 0; rep < 8; rep++) {
 #pragma unroll
       for (int i = 0; i < 8; i++) {
-        if (OP == FMA32) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+        if (OP == FMA32 || OP == FMA32_HALF) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
         if (OP == MUL32) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
-        if (OP == MIN32) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+        if (OP == MIN32 || OP == MIN32_HALF) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
         if (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b));  // reads vcc only (a clobber would make the compiler pad every one with s_nop)
         if (OP == MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(b));
         if (OP == PKFMA32) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p[i]) : "v"(p[(i + 1) & 7]));
@@ -215,6 +218,8 @@ int main() {
   rc |= run_op<CVT_F32_U32>(n_cu, sink, rec, h, json, false);
   rc |= run_op<CNDMASK_SGPR>(n_cu, sink, rec, h, json, false);
   rc |= run_op<MAX3>(n_cu, sink, rec, h, json, false);
+  rc |= run_op<FMA32_HALF>(n_cu, sink, rec, h, json, false);
+  rc |= run_op<MIN32_HALF>(n_cu, sink, rec, h, json, false);
   rc |= run_op<PKFMA32>(n_cu, sink, rec, h, json, false);
   rc |= run_op<PKMUL32>(n_cu, sink, rec, h, json, false);
   rc |= run_op<SQRT32>(n_cu, sink, rec, h, json, false);
