@@ -335,7 +335,7 @@ def cpu_baseline(pkg, wl, spp, args):
     return out
 
 
-def js_bvh_build(native, n_hint=None):
+def js_bvh_build(native):
     """The reference's one CPU loop — the median-split BVH build (lib/BVH/bvhNode.js:28-73) — as single-threaded JavaScript under
     Node on this box (js/bvh_time.mjs: the shipped restatement, byte-identical output to the reference's, tests/test_host_buffers.py)."""
     node = shutil.which("node") or shutil.which("nodejs")
@@ -354,21 +354,6 @@ def js_bvh_build(native, n_hint=None):
                 "reference": "lib/BVH/bvhNode.js:28-73; benchmarks.txt:19 quotes 4483 ms for the 297,972-triangle dragon in a browser"}
     finally:
         os.remove(f.name)
-
-
-def c2_mesh_boxes(pkg, native):
-    """Boxes of configs[1]'s mesh for the build timings: the golden triangles, padded as lib/BVH/AABB.js does (through the host mirror)."""
-    try:
-        sc = pkg.scenes.c2_scene() if hasattr(pkg.scenes, "c2_scene") else None
-    except Exception:
-        sc = None
-    if sc is None:
-        return False
-    try:
-        sc.buffers(native=native)
-        return native.boxes is not None
-    except Exception:
-        return False
 
 
 def main():
