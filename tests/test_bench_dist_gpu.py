@@ -34,3 +34,30 @@ def test_bench_two_ranks_on_one_gpu():
     assert three.returncode == 0, three.stderr[-2000:]
     c = json.loads([l for l in three.stdout.strip().splitlines() if l.startswith("{")][0])
     assert c["scaling"] == "strong" and c["config"]["rays_per_step"] == a["config"]["rays_per_step"]
+
+
+@pytest.mark.gpu
+def test_bench_line_contract_with_its_own_pmc_passes():
+    """The driver's line: contract keys, a roofline for the dominant kernel whose fractions come from rocprofv3 passes made by the run
+    itself (frac <= 1 by construction, in the unit of the bound it names), per-kernel table, CPU baselines incl. the single thread."""
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--width", "640", "--height", "360", "--spp", "8", "--cpu-seconds", "1",
+                        "--extra-configs", "off"], cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f32" and d["value"] > 0
+    roof = d["roofline"]
+    assert roof["kernel"] in ("k_generate", "k_bvh", "k_shade", "k_accumulate") and roof["avg_launch_ms"] > 0
+    tab = roof["kernels"]
+    assert abs(sum(v["share_of_kernel_time"] for v in tab.values()) - 1.0) < 1e-6
+    assert roof["kernel"] == max(tab, key=lambda k: tab[k]["ms_per_step"])
+    if "pmc_note" not in roof:  # rocprofv3 is on the GPU box: the passes must have produced the fractions
+        assert roof["bound"] in ("valu_issue", "hbm") and 0 < roof["frac"] <= 1 and roof["achieved"] <= roof["peak"] * (1 + 1e-9)
+        assert roof["traffic"] > 0 and "rocprofv3 --pmc passes made by this run" in roof["pmc_source"]
+        for v in tab.values():
+            assert 0 <= v["valu_busy_frac"] <= 1 and 0 <= v["hbm_frac"] <= 1 and 0 < v["active_lane_frac"] <= 1
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["single_thread"]["cores"] == 1 and cb["single_thread"]["value"] > 0
