@@ -316,32 +316,52 @@ int prepare_scene(ptmi_ctx* c) {
     int32_t r = 0;
     for (int i = 0; i < n_node; i++)
       if (seen[i] == 1) rank[i] = r++;
+    // Leaves that hold anything but one triangle (external / SAH trees) go through the leaf table; their entries are numbered
+    // first, in node order, so that the pair records below can be written by several host threads.
+    std::vector<int32_t> multi_ref;  // per node: index into the leaf table, -1 = not a multi-triangle leaf
+    for (int j = 0; j < n_node; j++) {
+      if (seen[j] != 2) continue;
+      const float* nd = &c->h_bvh[12 * (size_t)j];
+      const int cnt = (int)nd[9];
+      if (cnt == 1) continue;
+      if (multi_ref.empty()) multi_ref.assign((size_t)n_node, -1);
+      multi_ref[j] = (int32_t)(leaf_table.size() / 2);
+      leaf_table.push_back(cnt > 0 ? (int)nd[8] : 0);
+      leaf_table.push_back(cnt);
+    }
     auto ref_of = [&](int j) -> uint32_t {  // (every node passed the range checks of the walk above)
       const float* nd = &c->h_bvh[12 * (size_t)j];
       if (seen[j] == 1) return (uint32_t)rank[j];
-      int cnt = (int)nd[9];
-      if (cnt == 1) return REF_LEAF | (uint32_t)(int)nd[8];
-      leaf_table.push_back(cnt > 0 ? (int)nd[8] : 0);
-      leaf_table.push_back(cnt);
-      return REF_LEAF | REF_MULTI | (uint32_t)(leaf_table.size() / 2 - 1);
+      if ((int)nd[9] == 1) return REF_LEAF | (uint32_t)(int)nd[8];
+      return REF_LEAF | REF_MULTI | (uint32_t)multi_ref[j];
     };
     pairs.assign(16 * n_inner, 0.0f);
-    for (int i = 0; i < n_node; i++) {
-      if (seen[i] != 1) continue;
-      const float* nd = &c->h_bvh[12 * (size_t)i];
-      const int L = i + 1, R = (int)nd[3];
-      const float *nl = &c->h_bvh[12 * (size_t)L], *nr = &c->h_bvh[12 * (size_t)R];
-      float* o = &pairs[16 * (size_t)rank[i]];
-      uint32_t rl = ref_of(L), rr = ref_of(R);
-      int32_t axis = (int)nd[11];
-      o[0] = nl[0], o[1] = nl[1], o[2] = nl[2];
-      memcpy(&o[3], &rl, 4);
-      o[4] = nl[4], o[5] = nl[5], o[6] = nl[6];
-      memcpy(&o[7], &rr, 4);
-      o[8] = nr[0], o[9] = nr[1], o[10] = nr[2];
-      memcpy(&o[11], &axis, 4);
-      o[12] = nr[4], o[13] = nr[5], o[14] = nr[6];
-      o[15] = 0.0f;
+    auto fill_pairs = [&](int begin, int end) {
+      for (int i = begin; i < end; i++) {
+        if (seen[i] != 1) continue;
+        const float* nd = &c->h_bvh[12 * (size_t)i];
+        const int L = i + 1, R = (int)nd[3];
+        const float *nl = &c->h_bvh[12 * (size_t)L], *nr = &c->h_bvh[12 * (size_t)R];
+        float* o = &pairs[16 * (size_t)rank[i]];
+        uint32_t rl = ref_of(L), rr = ref_of(R);
+        int32_t axis = (int)nd[11];
+        o[0] = nl[0], o[1] = nl[1], o[2] = nl[2];
+        memcpy(&o[3], &rl, 4);
+        o[4] = nl[4], o[5] = nl[5], o[6] = nl[6];
+        memcpy(&o[7], &rr, 4);
+        o[8] = nr[0], o[9] = nr[1], o[10] = nr[2];
+        memcpy(&o[11], &axis, 4);
+        o[12] = nr[4], o[13] = nr[5], o[14] = nr[6];
+        o[15] = 0.0f;
+      }
+    };
+    {
+      const int nt = n_node < (1 << 16) ? 1 : (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+      std::vector<std::thread> th;
+      const int per = (n_node + nt - 1) / nt;
+      for (int k = 1; k < nt; k++) th.emplace_back(fill_pairs, std::min(n_node, k * per), std::min(n_node, (k + 1) * per));
+      fill_pairs(0, std::min(n_node, per));
+      for (auto& t : th) t.join();
     }
     const float* rn = &c->h_bvh[0];
     uint32_t rref = ref_of(0);
