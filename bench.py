@@ -481,6 +481,34 @@ def main():
     ctx.close()
 
     if rank == 0 and solo:
+        # Informational: the same workload through ONE context with two shards on this GPU (ptmi_create_multi with the device listed twice:
+        # two streams, pixel tiles dealt to them, summed at read-back) — the shards fill each other's k_bvh tails.  Not `value`: the kernels
+        # of the two streams overlap, so a per-kernel roofline of that mode would not mean what the one above means.
+        try:
+            ctx2 = pkg.Context([local, local])
+            ctx2.upload_scene(wl["buffers"])
+            ctx2.set_params(max_bounces=wl["bounces"], frames_in_flight=args.frames_in_flight, stack_size=wl["stack"], **wl["extra"])
+            ctx2.resize(wl["W"], wl["H"])
+
+            def step2():
+                ctx2.clear()
+                ctx2.render(wl["view"], 1, spp)
+                ctx2.synchronize()
+
+            for _ in range(max(1, min(args.warmup, 2))):
+                step2()
+            ctx2.reset_stats()
+            t2 = time.perf_counter()
+            n2 = max(1, min(args.steps, 10))
+            for _ in range(n2):
+                step2()
+            dt2 = time.perf_counter() - t2
+            st2 = ctx2.stats()
+            ctx2.close()
+            out["config"]["two_shards_on_one_gpu"] = {"value": st2["rays"] / dt2 / 1e6, "unit": "Mrays/s", "ms_per_step": dt2 / n2 * 1e3, "steps": n2,
+                                                      "note": "informational: one context, two streams (pixel tiles split in the library, bit-identical image); not the headline value"}
+        except Exception as e:  # never let the extra leg cost the line
+            out["config"]["two_shards_on_one_gpu"] = {"error": str(e)[:200]}
         setup = {args.workload: wl["setup"]}
         if extra_c3:
             wl3, ctx3, spp3, per3, m3 = run_workload("c3", 2, 1, 0)
