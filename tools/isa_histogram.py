@@ -78,7 +78,7 @@ def issue_weights():
 
 def assembly(src=None, out="/tmp/ptmi_isa.s"):
     src = src or os.path.join(ROOT, "webgpu-path-tracer_amd", "csrc", "ptmi.hip")
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-command-line-argument"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-Wno-unused-command-line-argument"]
     subprocess.run(["hipcc"] + flags + ["--cuda-device-only", "-S", "-o", out, src], check=True)
     return open(out).read().splitlines()
 

@@ -3,7 +3,7 @@
 tag=$1; ctrs=$2; shift 2
 out=/tmp/pmc_$tag; rm -rf $out; mkdir -p $out gpurun_out
 export TMPDIR=/tmp
-rocprofv3 --pmc $ctrs --output-format csv -d $out -o run -- python3 bench.py "$@" > gpurun_out/pmc_${tag}.log 2>&1
+timeout -k 10 ${PMC_TIMEOUT:-240} rocprofv3 --pmc $ctrs --output-format csv -d $out -o run -- python3 bench.py "$@" > gpurun_out/pmc_${tag}.log 2>&1
 python3 - "$out" "gpurun_out/pmc_${tag}.json" <<'PY'
 import csv, glob, json, sys, collections, re
 out, dst = sys.argv[1], sys.argv[2]

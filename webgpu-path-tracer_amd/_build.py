@@ -19,6 +19,9 @@ ADDON = os.path.join(PKG, "js", "ptmi.node")
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
+    # no SLP vectoriser: on gfx950 a packed-f32 instruction issues in 4 cycles, the two scalar ones it replaces in 2 + 2, and the
+    # packing costs moves and registers (k_bvh 92 -> 68 VGPRs, k_shade 92 -> 79, k_shade -6 %, k_generate -10 %; tools/kernel_resources.sh)
+    "-fno-slp-vectorize",
     "-Wall", "-Wno-unused-function",
 ]
 

@@ -536,8 +536,18 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
   HIP_TRY(c, c->d_spill.ensure(std::max<size_t>(16, (size_t)grid * (size_t)se * 64 * sizeof(int2))));
   const int thr = env_int("PTMI_REFILL", kRefillThreshold);
   const int leaf_batch = env_int("PTMI_LEAF_BATCH", kLeafBatch);
-#define PTMI_LAUNCH_BVH(CNT, NA) \
-  hipLaunchKernelGGL((k_bvh<CNT, NA>), dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), n_teams, c->prm.stack_size, le, se, c->d_spill.as<int2>(), thr, leaf_batch, tot)
+  // PTMI_BVH_KERNEL: 1 = the first edition of the traversal kernel (rounds 1/2), 2 = second edition with one unified fetch per iteration,
+  // 3 (default) = second edition's state machine in the first edition's two-phase loop — for A/B runs
+  const int edition = env_int("PTMI_BVH_KERNEL", 3);
+#define PTMI_LAUNCH_BVH_K(KERNEL)                                                                                                                                     \
+  hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), n_teams, c->prm.stack_size, le, se, c->d_spill.as<int2>(), thr, \
+                     leaf_batch, tot)
+#define PTMI_LAUNCH_BVH(CNT, NA)                                       \
+  do {                                                                 \
+    if (edition == 1) PTMI_LAUNCH_BVH_K((k_bvh<CNT, NA>));            \
+    else if (edition == 2) PTMI_LAUNCH_BVH_K((k_bvh2<CNT, NA, true>)); \
+    else PTMI_LAUNCH_BVH_K((k_bvh2<CNT, NA, false>));                  \
+  } while (0)
   if (c->counters) {
     if (noabort) PTMI_LAUNCH_BVH(true, true);
     else PTMI_LAUNCH_BVH(true, false);
@@ -546,6 +556,7 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
     else PTMI_LAUNCH_BVH(false, false);
   }
 #undef PTMI_LAUNCH_BVH
+#undef PTMI_LAUNCH_BVH_K
   HIP_TRY(c, hipGetLastError());
   return PTMI_OK;
 }

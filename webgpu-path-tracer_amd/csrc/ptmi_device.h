@@ -660,6 +660,125 @@ DEV void trav_inner_phase(const DevScene& S, int stack_size, const LaneStack& st
   trav_pop_until_pass(stk, t, cn, COUNT);
 }
 
+// ---- second edition of the traversal state machine (k_bvh2) -----------------------------------------------------------
+// Same visits, same outcomes, same counters as trav_inner_phase / trav_leaf_phase / trav_pop_until_pass; what changed is how
+// the wave spends its instructions (round-2 profile: the pop loop — two FLAT loads per attempt because the LDS / spill choice
+// had been folded into one generic pointer, ~45 instructions per attempt at 7-25 % active lanes — cost as many issue slots as
+// the slab tests, and every triangle phase was a memory round trip of its own):
+//   * one state word per lane: pair index of an inner node whose box has passed | leaf ref (REF_LEAF set) whose triangles are
+//     still to be tested | N_POP | N_DONE;
+//   * a stack entry is 8 contiguous bytes per lane (entry e of lane l at int2 index e*64 + l): ds_read_b64 / ds_write_b64, always
+//     an LDS instruction; the rare deeper entries (per-wave spill area in global memory) are a separate, skipped branch;
+constexpr uint32_t N_DONE = 0x7fffffffu, N_POP = 0x7ffffffeu, N_INNER_LIMIT = 0x10000000u;
+// The LDS part is addressed through an explicit address-space-3 pointer: with a generic one the compiler folded the LDS / spill choice
+// into FLAT loads and stores (both pipes, both counters) — the round-2 kernel's pop did exactly that.
+typedef v2i_t __attribute__((address_space(3))) lds_v2i_t;
+struct LaneStack2 {
+  lds_v2i_t* lds;
+  int2* spill;
+  int lds_entries;
+};
+DEV void stack2_write(const LaneStack2& k, int e, uint32_t w0, float w1) {
+  if (e < k.lds_entries) {
+    v2i_t v;
+    v.x = (int)w0, v.y = __float_as_int(w1);
+    k.lds[e * 64] = v;
+  } else {
+    k.spill[(e - k.lds_entries) * 64] = make_int2((int)w0, __float_as_int(w1));
+  }
+}
+DEV void stack2_read(const LaneStack2& k, int e, uint32_t& w0, float& w1) {
+  const v2i_t v = k.lds[min(e, k.lds_entries - 1) * 64];
+  w0 = (uint32_t)v.x;
+  w1 = __int_as_float(v.y);
+  if (e >= k.lds_entries) {
+    const int2 g = k.spill[(e - k.lds_entries) * 64];
+    w0 = (uint32_t)g.x;
+    w1 = __int_as_float(g.y);
+  }
+}
+
+// One reference visit of an inner node's near child (boxes in the fetched pair record), far child pushed: trav_inner_phase
+// without its fetch and without the pops.  Returns the lane's next state word.
+template <bool COUNT, bool NOABORT>
+DEV uint32_t inner_step2(float4 f0, float4 f1, float4 f2, float4 f3v, f3 o, f3 inv, uint32_t negmask, float ct, int stack_size, const LaneStack2& stk, int& sp,
+                         Counters& cn) {
+  float tsL, tbL, tsR, tbR;
+  slab(f0, f1, o, inv, tsL, tbL);
+  slab(f2, f3v, o, inv, tsR, tbR);
+  const int axis = __float_as_int(f2.w);
+  const bool neg = ((negmask >> axis) & 1u) != 0u;
+  const uint32_t refL = __float_as_uint(f0.w), refR = __float_as_uint(f1.w);
+  const uint32_t nearRef = neg ? refR : refL;
+  uint32_t farRef = neg ? refL : refR;
+  const float tsN = neg ? tsR : tsL, tbN = neg ? tbR : tbL;
+  const float tsF = neg ? tsL : tsR, tbF = neg ? tbL : tbR;
+  const bool fB = tbF > tsF;
+  const bool fA = fB || (tbF != tbF);
+  farRef |= (fA ? REF_A : 0u) | (fB ? REF_B : 0u);
+  if (NOABORT) {
+    if (fA) {
+      stack2_write(stk, sp, farRef, tsF);
+      sp++;
+    } else if (COUNT) {
+      cn.node_visits++;  // the pop + failed re-test the reference performs later
+    }
+  } else {
+    stack2_write(stk, sp, farRef, tsF);
+    sp++;
+    if (sp >= stack_size) return N_DONE;  // Q7
+  }
+  if (COUNT) cn.node_visits++;
+  return (ptm_min(ct, tbN) > tsN) ? nearRef : N_POP;  // a leaf ref has REF_LEAF set, an inner ref is the pair index
+}
+
+// Pops until an entry passes its re-test against the current closest hit (or the stack is empty): trav_pop_until_pass.
+DEV uint32_t pop_until_pass2(const LaneStack2& stk, int& sp, float ct, Counters& cn, bool count) {
+  uint32_t node = N_POP;
+  while (node == N_POP) {
+    if (sp == 0) {
+      node = N_DONE;
+      break;
+    }
+    sp--;
+    uint32_t e;
+    float ts;
+    stack2_read(stk, sp, e, ts);
+    if (count) cn.node_visits++;
+    const bool pass = (((e & REF_A) != 0u) & (ct > ts)) | ((ct != ct) & ((e & REF_B) != 0u));
+    if (pass) node = (e & REF_LEAF) ? e : (e & REF_IDX);
+  }
+  return node;
+}
+
+// hit_triangle on a fetched pretri record (same arithmetic as tri_record_test), state in plain registers.
+struct TriHit {
+  float u, v;
+  uint32_t prim, mat;  // prim == 0: no triangle accepted yet
+};
+template <bool COUNT>
+DEV void tri_test2(const DevScene& S, int k, float4 t0, float4 t1, float4 t2, float4 t3, f3 o, f3 d, ObjRay& orr, float& ct, TriHit& h, Counters& cn) {
+  int mesh = __float_as_int(t0.w);
+  if (mesh != orr.mesh) obj_ray_for(S, mesh, __float_as_int(t2.w), o, d, orr);
+  if (COUNT) cn.tri_tests++;
+  f3 A = mk3(t0), AB = mk3(t1), AC = mk3(t2), N = mk3(t3);
+  float det = -dot3(orr.d, N);
+  if (ptm_abs(det) < kTmin) return;
+  f3 ao = orr.o - A;
+  f3 dao = cross3(ao, orr.d);
+  float invDet = rcp_exact_il(det);
+  float dst = dot3(ao, N) * invDet;
+  float u = dot3(AC, dao) * invDet;
+  float v = -dot3(AB, dao) * invDet;
+  float w = 1.0f - u - v;
+  if (dst < kTmin || dst > ct || u < kTmin || v < kTmin || w < kTmin) return;
+  ct = dst;
+  h.u = u, h.v = v;
+  h.prim = (K_TRI << 28) | (uint32_t)k;
+  h.mat = __float_as_uint(t1.w);
+  if (COUNT) cn.mat_fetches++;
+}
+
 // ---- HitRecord reconstruction (the accepting branch of the winning primitive test) ------------------
 struct HitGeom {
   f3 p, n;

@@ -263,6 +263,172 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
   if (COUNT) reduce_counters(cn, totals, true);
 }
 
+// k_bvh, second edition (round 3).  Same scheduling (persistent single-wave blocks, team counters, flag scan, ballot refill),
+// same per-ray visit order, outcomes and counters; three changes to where the instructions and the round trips go:
+//   * ONE fetch per lane per iteration whatever the lane is about to do — the pair record of its inner node or the pretri record
+//     of its pending triangle (both 4 x float4) — so a triangle phase is no longer a memory round trip of its own: a lane with a
+//     pending leaf fetches its record with everybody else's next fetch and keeps it in the same registers until the triangle
+//     batch is due (exec-masked loads leave the other lanes' registers alone);
+//   * one shared pop section behind both kinds of step, on 8-byte LDS stack entries (ptmi_device.h).
+// (Storing an accepted hit at once instead of at the end of the ray saved four registers and lost 12 %: on gfx9 stores count on
+// vmcnt like loads, so every later fetch waited for them.)
+template <bool COUNT, bool NOABORT, bool UNIFIED>
+__global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads, uint32_t n_teams, int stack_size,
+                                                           int lds_entries, int spill_entries, int2* __restrict__ spill, int refill_threshold, int leaf_batch,
+                                                           unsigned long long* __restrict__ totals) {
+  extern __shared__ int lds_stack[];
+  const int lane = lane_id();
+  LaneStack2 stk;
+  stk.lds = (lds_v2i_t*)lds_stack + lane;
+  stk.spill = spill + (size_t)blockIdx.x * (size_t)spill_entries * 64 + lane;
+  stk.lds_entries = lds_entries;
+  uint32_t* cand = reinterpret_cast<uint32_t*>(lds_stack + lds_entries * 2 * 64);  // [128] candidate slots
+  const uint32_t n = ctl->n_rays;
+  const uint32_t range = min(kBvhRange, max(64u, ((n / (2u * gridDim.x)) + 63u) & ~63u));
+  const uint32_t team = blockIdx.x % n_teams;
+  Counters cn = {0, 0, 0, 0, 0};
+  uint32_t rb = 0, re = 0;   // this wave's claimed range of slots still to be scanned (wave-uniform)
+  uint32_t ncand = 0;        // candidates waiting in `cand` (wave-uniform)
+  bool exhausted = (n == 0);
+  // the lane's ray
+  uint32_t node = N_DONE, myslot = 0, negmask = 0;
+  int sp = 0;
+  f3 o = mk3(0, 0, 0), d = o, inv = o;
+  float ct = 0.0f;
+  ObjRay orr;
+  orr.mesh = -1;
+  orr.o = orr.d = o;
+  TriHit hit = {0.0f, 0.0f, 0u, 0u};
+  bool has = false;  // this lane holds a ray (traversing, or finished and not yet retired)
+  const uint32_t root = __float_as_uint(S.root_lo.w);
+  const uint32_t root_node = (root & REF_LEAF) ? root : (root & REF_IDX);
+  for (;;) {
+    // retire finished rays (stores only): a triangle beat what part 1 had found; otherwise the record stands as it is
+    if (has && node == N_DONE) {
+      if (hit.prim != 0u) {
+        P.hin.tp[myslot] = make_float2(ct, __uint_as_float(hit.prim));
+        P.uv[myslot] = make_float2(hit.u, hit.v);
+        P.hin.mat[myslot] = hit.mat;
+      }
+      has = false;
+    }
+    uint64_t hm = __ballot(node != N_DONE);
+    int nact = __popcll(hm);
+    if ((64 - nact) >= (nact == 0 ? 1 : refill_threshold)) {
+      const uint32_t want = (uint32_t)(64 - nact);
+      while (ncand < want && !(exhausted && rb == re)) {
+        if (rb == re) {  // claim the next range of slots (see k_bvh)
+          uint32_t i = 0;
+          if (lane == 0) i = atomicAdd(&heads[team * kHeadStride], 1u);
+          i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+          const uint64_t nb64 = ((uint64_t)team + (uint64_t)n_teams * i) * range;
+          if (nb64 >= (uint64_t)n) {
+            exhausted = true;
+            continue;
+          }
+          const uint32_t nb = (uint32_t)nb64;
+          rb = nb;
+          re = min(nb + range, n);
+        }
+        const uint32_t slot = rb + (uint32_t)lane;
+        const bool flagged = slot < re && (P.hin.mat[slot] & HITMAT_BVH) != 0u;
+        const uint64_t fm = __ballot(flagged);
+        if (flagged) cand[ncand + lanes_below(fm)] = slot;
+        ncand += (uint32_t)__popcll(fm);
+        rb = min(rb + 64u, re);
+      }
+      if (ncand) {
+        const uint64_t idle = ~hm;
+        const uint32_t k = lanes_below(idle);
+        const uint32_t take = min(ncand, want);
+        if (node == N_DONE && k < take) {
+          myslot = cand[ncand - 1u - k];
+          const float4 r0 = P.in.q0[myslot], r1 = P.in.q1[myslot];
+          ct = P.hin.tp[myslot].x;  // closest_so_far after part 1 of hitScene; the rest of that record stands unless a triangle wins
+          o = mk3(r0);
+          d = mk3(r1);
+          inv = rcp3_exact_il(d);
+          negmask = (d.x < 0 ? 1u : 0u) | (d.y < 0 ? 2u : 0u) | (d.z < 0 ? 4u : 0u);
+          orr.mesh = -1;
+          sp = 0;
+          hit.prim = 0u;
+          has = true;
+          node = root_node;
+        }
+        ncand -= take;
+        hm = __ballot(node != N_DONE);
+        nact = __popcll(hm);
+      }
+    }
+    if (nact == 0) break;  // nothing in flight, nothing buffered, queue exhausted
+    const bool more = ncand > 0 || !(exhausted && rb == re);
+    const int min_working = more ? (64 - refill_threshold + 1) : 1;
+    int working;
+    if (UNIFIED) {
+    float4 f0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), f1 = f0, f2 = f0, f3v = f0;
+    bool fetched = false;  // f0..f3v hold the pretri record of this lane's pending triangle
+    do {
+      const bool isinner = node < N_INNER_LIMIT;
+      const bool isleaf = (int)node < 0;
+      const bool simple = isleaf && !(node & REF_MULTI);
+      if (isinner || (simple && !fetched)) {
+        const float4* rec = simple ? S.pretri + 4 * (size_t)(node & REF_IDX) : S.pairs + 4 * (size_t)node;
+        f0 = rec[0], f1 = rec[1], f2 = rec[2], f3v = rec[3];
+        fetched = simple;
+      }
+      const uint64_t pm = __ballot(isleaf), im = __ballot(isinner);
+      // triangles only when a batch of lanes waits for them, or nothing else can run
+      const bool run_leaf = pm != 0ull && (__popcll(pm) >= leaf_batch || im == 0ull);
+      uint32_t next = node;
+      if (isinner) next = inner_step2<COUNT, NOABORT>(f0, f1, f2, f3v, o, inv, negmask, ct, stack_size, stk, sp, cn);
+      if (run_leaf && isleaf) {
+        if (simple) {
+          tri_test2<COUNT>(S, (int)(node & REF_IDX), f0, f1, f2, f3v, o, d, orr, ct, hit, cn);
+        } else {  // prim_count != 1 (external / SAH trees): rare
+          const int2 lc = S.leaf_table[node & REF_IDX];
+          for (int j = 0; j < lc.y; j++) {
+            const float4* rec = S.pretri + 4 * (size_t)(lc.x + j);
+            const float4 g0 = rec[0], g1 = rec[1], g2 = rec[2], g3 = rec[3];
+            tri_test2<COUNT>(S, lc.x + j, g0, g1, g2, g3, o, d, orr, ct, hit, cn);
+          }
+        }
+        fetched = false;
+        next = N_POP;
+      }
+      if (next == N_POP) next = pop_until_pass2(stk, sp, ct, cn, COUNT);
+      node = next;
+      working = __popcll(__ballot(node != N_DONE));
+    } while (working >= min_working);
+    } else {
+    // Two phases per iteration, each with its own fetch, as in the first edition: the triangle records are the coldest data of the
+    // scene, and a wave waits for the slowest lane of a fetch — mixing them into every pair fetch (UNIFIED) made every wait a slow one
+    // (configs[3]: 581 ms against 514 per 128 spp although it issues 11 % fewer vector and 46 % fewer memory instructions).
+    do {
+      const uint64_t pm = __ballot((int)node < 0), im = __ballot(node < N_INNER_LIMIT);
+      if (pm != 0ull && (__popcll(pm) >= leaf_batch || im == 0ull)) {
+        if ((int)node < 0) {
+          const int2 lc = (node & REF_MULTI) ? S.leaf_table[node & REF_IDX] : make_int2((int)(node & REF_IDX), 1);
+          for (int j = 0; j < lc.y; j++) {  // one triangle per leaf with the reference's builder
+            const float4* rec = S.pretri + 4 * (size_t)(lc.x + j);
+            const float4 g0 = rec[0], g1 = rec[1], g2 = rec[2], g3 = rec[3];
+            tri_test2<COUNT>(S, lc.x + j, g0, g1, g2, g3, o, d, orr, ct, hit, cn);
+          }
+          node = pop_until_pass2(stk, sp, ct, cn, COUNT);
+        }
+      }
+      if (node < N_INNER_LIMIT) {
+        const float4* rec = S.pairs + 4 * (size_t)node;
+        const float4 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3v = rec[3];
+        node = inner_step2<COUNT, NOABORT>(f0, f1, f2, f3v, o, inv, negmask, ct, stack_size, stk, sp, cn);
+        if (node == N_POP) node = pop_until_pass2(stk, sp, ct, cn, COUNT);
+      }
+      working = __popcll(__ballot(node != N_DONE));
+    } while (working >= min_working);
+    }
+  }
+  if (COUNT) reduce_counters(cn, totals, true);
+}
+
 // What a surviving path carries into the next step's queue.
 struct NewState {
   f3 o, d, T;
