@@ -76,6 +76,7 @@ def make_workload(pkg, name, args):
     """Scene buffers + parameters of one BASELINE configuration."""
     wl = {"name": name, "cam": "cornell", "extra": {}, "W": args.width, "H": args.height, "bounces": args.bounces, "setup": {}}
     sah = args.bvh == "sah"
+    tri_kw = {"n_tris": args.tris} if args.tris else {}  # experiments only: the configurations' own triangle counts are the default
     t0 = time.perf_counter()
     native = TimedNative(pkg.ptmi.NativeHost())
     if name == "c2":
@@ -84,13 +85,13 @@ def make_workload(pkg, name, args):
         wl["buffers"] = pkg.scenes.golden_buffers("c2")  # reference-generated buffers of configs[1] (tests/golden)
         wl["label"], wl["stack"] = "configs[1]: Cornell + monkey_968.obj (967 tris)", args.stack_size or 20
     elif name == "c3":
-        wl["buffers"] = pkg.scenes.c3_scene().buffers(native=native, sah=sah)  # procedural stand-in, 871,414 tris
+        wl["buffers"] = pkg.scenes.c3_scene(**tri_kw).buffers(native=native, sah=sah)  # procedural stand-in, 871,414 tris
         wl["label"], wl["stack"] = "configs[2]: Cornell + dragon-class mesh (871,414 tris, procedural stand-in for stanfordDragon.obj)", args.stack_size or 24
     elif name == "c4":
-        wl["buffers"] = pkg.scenes.c4_scene().buffers(native=native, sah=sah)
+        wl["buffers"] = pkg.scenes.c4_scene(**tri_kw).buffers(native=native, sah=sah)
         wl["label"], wl["stack"], wl["cam"] = "configs[3]: sponza-class interior (262,267 tris, procedural stand-in for sponzaAtrium.obj), camera inside", args.stack_size or 24, "interior"
     else:
-        wl["buffers"] = pkg.scenes.c5_scene().buffers(native=native, sah=sah)
+        wl["buffers"] = pkg.scenes.c5_scene(**tri_kw).buffers(native=native, sah=sah)
         wl["label"], wl["stack"], wl["extra"] = "configs[4]: Cornell + buddha-class glass mesh (1,087,716 tris, procedural stand-in for buddha.obj), importance sampling", args.stack_size or 24, dict(importance_sampling=1)
         if wl["bounces"] == 8:
             wl["bounces"] = 16
@@ -155,7 +156,7 @@ def pmc_passes(args, workload, log):
         d = tempfile.mkdtemp(prefix="ptmi_pmc_%s_" % tag, dir="/tmp")
         cmd = [rocprof, "--pmc"] + ctrs.split() + ["--output-format", "csv", "-d", d, "-o", "run", "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
                                                   "--workload", workload, "--width", str(args.width), "--height", str(args.height), "--bounces", str(args.bounces),
-                                                  "--frames-in-flight", str(args.frames_in_flight), "--bvh", args.bvh, "--stack-size", str(args.stack_size),
+                                                  "--frames-in-flight", str(args.frames_in_flight), "--bvh", args.bvh, "--stack-size", str(args.stack_size), "--tris", str(args.tris),
                                                   "--spp", str(args.spp if workload == args.workload else 0)]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=args.pmc_timeout)
@@ -369,6 +370,7 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="progressive frames per step (0 = the config's: 64 for c2, 256 for c3, 512 for c4, 1024 for c5); per GPU with --scaling weak, in total with strong")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: weak = spp x N (fixed rays per GPU), strong = fixed total spp (fixed total rays)")
     ap.add_argument("--stack-size", type=int, default=0)
+    ap.add_argument("--tris", type=int, default=0, help="experiments: tessellate the procedural mesh of c3/c4/c5 to this many triangles (0 = the configuration's count)")
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--frames-in-flight", type=int, default=0)
     ap.add_argument("--bvh", default="median", choices=["median", "sah"],

@@ -6,8 +6,8 @@
 //             instructions for the quad's four records: each wave-instruction touches 16 lines with 64 contiguous bytes each
 //   quad_lds  `quad`, then a 4x4 transpose through LDS (4 x ds_write_b128, 4 x ds_read_b128) so that every lane ends up with
 //             its own record in registers — the full price of the cooperative form
-// Every lane follows a dependent chain (the next index depends on the loaded data, as a traversal's does); tables of 2 MB
-// (L2-resident per XCD), 32 MB, 128 MB (Infinity Cache) and 2 GB; 5 single-wave-per-SIMD-slot blocks of 256 threads per CU.
+// Every lane follows a dependent chain (the next index depends on the loaded data, as a traversal's does); tables of 8 KB and 64 KB
+// (L1-resident), 512 KB and 2 MB (L2-resident per XCD), 32 MB, 128 MB (Infinity Cache) and 2 GB; 5 single-wave-per-SIMD-slot blocks of 256 threads per CU.
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/gather_probe tools/gather_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -69,7 +69,7 @@ int main() {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  const size_t sizes[] = {(size_t)2 << 20, (size_t)32 << 20, (size_t)128 << 20, (size_t)2 << 30};
+  const size_t sizes[] = {(size_t)8 << 10, (size_t)64 << 10, (size_t)512 << 10, (size_t)2 << 20, (size_t)32 << 20, (size_t)128 << 20, (size_t)2 << 30};
   const char* names[] = {"lane", "quad", "quad_lds"};
   printf("{\"cus\": %d, \"clock_mhz\": %d, \"cases\": [\n", cus, prop.clockRate / 1000);
   bool first = true;
@@ -90,8 +90,8 @@ int main() {
         float ms = 0;
         CK(hipEventElapsedTime(&ms, e0, e1));
         const double recs = (double)cus * bpc * 256 * steps;
-        printf("%s {\"mode\": \"%s\", \"table_mb\": %zu, \"waves_per_simd\": %d, \"ms\": %.3f, \"grecords_per_s\": %.2f, \"tb_per_s\": %.2f, \"cycles_per_record_per_cu\": %.2f}",
-               first ? "" : ",\n", names[mode], bytes >> 20, bpc, ms, recs / ms / 1e6, recs * 64 / ms / 1e9, ms * 1e-3 * (prop.clockRate * 1e3) / (recs / cus));
+        printf("%s {\"mode\": \"%s\", \"table_kb\": %zu, \"waves_per_simd\": %d, \"ms\": %.3f, \"grecords_per_s\": %.2f, \"tb_per_s\": %.2f, \"cycles_per_record_per_cu\": %.2f}",
+               first ? "" : ",\n", names[mode], bytes >> 10, bpc, ms, recs / ms / 1e6, recs * 64 / ms / 1e9, ms * 1e-3 * (prop.clockRate * 1e3) / (recs / cus));
         first = false;
         fflush(stdout);
       }

@@ -12,3 +12,11 @@ for k, v in sorted(d.items(), key=lambda kv: -kv[1].get("ms_total", 0))[:4]:
         sys.argv[2], k[:36], v["ms_total"], v["SQ_INSTS_VALU"], v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]), v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"],
         4.0 * v["SQ_ACTIVE_INST_VALU"] / 1024 / (v["SQ_BUSY_CYCLES"] / 32.0), v["SQ_INSTS_VMEM_RD"], v["SQ_INSTS_LDS"]))
 PY
+python3 - gpurun_out/pmc_sq_$tag.json $tag <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+for k, v in d.items():
+    if "k_bvh" in k and "SQ_WAVE_CYCLES" in v:
+        cyc = v["SQ_BUSY_CYCLES"] / 32.0
+        print("%-10s %-36s avg waves/CU %.1f  VALU/cycle/SIMD %.3f  clock %.2f GHz" % (sys.argv[2], k[:36], 4 * v["SQ_WAVE_CYCLES"] / cyc / 256, v["SQ_INSTS_VALU"] / cyc / 1024, cyc / (v["ms_total"] * 1e-3) / 1e9))
+PY

@@ -76,6 +76,7 @@ struct ptmi_ctx {
   int bvh_depth = 0;             // max number of inner nodes on a root-to-leaf path
   bool has_unknown_material = false;
   int material_classes = 0;      // distinct shade bins among the materials: k_shade sorts only when > 1
+  int shade_blocks_per_cu[16] = {0};  // per k_shade variant: resident 256-thread blocks per CU (0 = not asked yet)
 
   int W = 0, H = 0;
   DBuf d_fb_own;
@@ -495,6 +496,18 @@ Paths paths_of(ptmi_ctx* c, int step, bool with_pixsum) {
   return P;
 }
 
+// the k_shade instance for a parameter combination (occupancy queries)
+const void* shade_kernel(bool is, bool so, bool cn, bool mu) {
+#define PTMI_SK(I, S, C, M) \
+  if (is == I && so == S && cn == C && mu == M) return reinterpret_cast<const void*>(&k_shade<I, S, C, M>)
+  PTMI_SK(false, false, false, false); PTMI_SK(false, false, false, true); PTMI_SK(false, false, true, false); PTMI_SK(false, false, true, true);
+  PTMI_SK(false, true, false, false); PTMI_SK(false, true, false, true); PTMI_SK(false, true, true, false); PTMI_SK(false, true, true, true);
+  PTMI_SK(true, false, false, false); PTMI_SK(true, false, false, true); PTMI_SK(true, false, true, false); PTMI_SK(true, false, true, true);
+  PTMI_SK(true, true, false, false); PTMI_SK(true, true, false, true); PTMI_SK(true, true, true, false); PTMI_SK(true, true, true, true);
+#undef PTMI_SK
+  return nullptr;
+}
+
 int stack_alloc_for(const ptmi_ctx* c) { return std::max(1, std::min(c->prm.stack_size, std::max(c->bvh_depth, 1))); }
 
 int env_int(const char* name, int dflt) {
@@ -515,8 +528,10 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
   if (c->S.n_nodes <= 0) return PTMI_OK;
   ScopedSpan sp(c, T_BVH);
   // Stack entries per lane: the first kLdsStackEntries in LDS, the rest (rarely reached) in a per-wave spill area.
-  // 14 entries x 512 B + the candidate buffer = 7.5 KB per wave: 20 waves (5 per SIMD, the VGPR limit) fit a CU's 160 KB.
-  constexpr int kLdsStackEntries = 14;
+  // 10 entries x 512 B + the candidate buffer = 5.5 KB per wave: 28 waves fit a CU's 160 KB, and the second-edition kernel's 66 VGPRs
+  // admit 7 waves per SIMD.  (Round 3: the kernel runs at the rate of the CU's L1 gather path — tools/gather_probe*.hip, 2.8 clocks per
+  // 64-byte record — so occupancy beyond ~18 waves buys 0-3 %: configs[1] 4.53 -> 4.18 ms, configs[3] 482 -> 481.)
+  constexpr int kLdsStackEntries = 10;
   const int sa = stack_alloc_for(c);
   const int le = std::min(sa, std::max(1, env_int("PTMI_LDS_STACK", kLdsStackEntries)));
   const int se = sa - le;
@@ -524,8 +539,8 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
   // The abort of Q7 (hitRay.wgsl:106-109) needs sp to reach STACK_SIZE; sp never exceeds the number of inner nodes on a
   // root-to-leaf path.  PTMI_NOABORT=0 keeps the literal stack discipline for A/B runs.
   const bool noabort = c->bvh_depth < c->prm.stack_size && env_int("PTMI_NOABORT", 1) != 0;
-  // VGPR budget: <= 96 VGPRs (5 waves/SIMD)
-  int waves_per_cu = (int)std::min<size_t>(20, (size_t)(160 * 1024) / (lds + 64));
+  const int edition = env_int("PTMI_BVH_KERNEL", 3);
+  int waves_per_cu = (int)std::min<size_t>(edition == 3 ? 28 : 20, (size_t)(160 * 1024) / (lds + 64));  // (editions 1 and 2 need 68-84 VGPRs)
   if (env_int("PTMI_WAVES_PER_CU", 0) > 0) waves_per_cu = env_int("PTMI_WAVES_PER_CU", 0);  // tuning aid; 0/unset = auto
   const uint32_t want = (max_items + 63) / 64;
   const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(want, (uint32_t)c->num_cus * (uint32_t)waves_per_cu));
@@ -538,7 +553,6 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
   const int leaf_batch = env_int("PTMI_LEAF_BATCH", kLeafBatch);
   // PTMI_BVH_KERNEL: 1 = the first edition of the traversal kernel (rounds 1/2), 2 = second edition with one unified fetch per iteration,
   // 3 (default) = second edition's state machine in the first edition's two-phase loop — for A/B runs
-  const int edition = env_int("PTMI_BVH_KERNEL", 3);
 #define PTMI_LAUNCH_BVH_K(KERNEL)                                                                                                                                     \
   hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), n_teams, c->prm.stack_size, le, se, c->d_spill.as<int2>(), thr, \
                      leaf_batch, tot)
@@ -605,12 +619,25 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   const uint32_t total = rc.n_local * (uint32_t)n_frames;
   const uint32_t bound = total + total / 8 + (uint32_t)c->num_cus * 8 * 1024;  // slots a step's queue can span
   const uint32_t ew_grid = std::max<uint32_t>(1, std::min<uint32_t>((total + kBlock - 1) / kBlock, (uint32_t)c->num_cus * 16));
-  const uint32_t sgrid = std::max<uint32_t>(1, std::min<uint32_t>((bound + kSChunk - 1) / kSChunk, (uint32_t)c->num_cus * (uint32_t)std::min(8, std::max(1, env_int("PTMI_SHADE_BLOCKS_PER_CU", 5)))));  // <= 8: the queue buffers' slack is sized for that (ensure_paths)
-  unsigned long long* tot = c->d_totals.as<unsigned long long>();
-
   // k_shade sorts its chunks by material class only when the scene has more than one (PTMI_SORT=0/1 overrides, for A/B runs)
   const int sort_env = env_int("PTMI_SORT", -1);
   const bool sort = sort_env >= 0 ? sort_env != 0 : c->material_classes > 1;
+
+  // k_shade's grid: as many blocks per CU as the variant's registers and LDS admit (the progressive-mode variants need 79 VGPRs since
+  // the build dropped the SLP vectoriser: 6 blocks = 6 waves per SIMD; the importance-sampling ones 93: 5) — asked of the runtime once per variant
+  const bool shade_multi = rc.num_samples > 1;
+  int shade_bpc = env_int("PTMI_SHADE_BLOCKS_PER_CU", 0);
+  if (shade_bpc <= 0) {
+    int& cached = c->shade_blocks_per_cu[(p.importance_sampling ? 8 : 0) | (sort ? 4 : 0) | (c->counters ? 2 : 0) | (shade_multi ? 1 : 0)];
+    if (cached == 0) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, shade_kernel(p.importance_sampling != 0, sort, c->counters, shade_multi), kBlock, 0) != hipSuccess || nb < 1) nb = 5;
+      cached = nb;
+    }
+    shade_bpc = cached;
+  }
+  const uint32_t sgrid = std::max<uint32_t>(1, std::min<uint32_t>((bound + kSChunk - 1) / kSChunk, (uint32_t)c->num_cus * (uint32_t)std::min(8, std::max(1, shade_bpc))));  // <= 8: the queue buffers' slack is sized for that (ensure_paths)
+  unsigned long long* tot = c->d_totals.as<unsigned long long>();
 
   ScopedSpan whole(c, T_RENDER);
   c->batch_enqueued = true;  // from here on a failure leaves a partly traced batch behind: never retried
