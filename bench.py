@@ -172,6 +172,7 @@ def pmc_passes(args, workload, log):
         for f in files:
             for row in csv.DictReader(open(f)):
                 k = row["Kernel_Name"].replace("ptmi::", "").replace("void ", "").split("(")[0].strip().split("<")[0]
+                k = {"k_bvh2": "k_bvh"}.get(k, k)  # the traversal kernel's second edition (round 3) is the same pipeline stage
                 if k not in KERNELS:
                     continue
                 rec = out.setdefault(k, {})
@@ -255,21 +256,30 @@ def roofline_of(tab, dom, timed_ms_per_launch, timed_launches):
 
 
 # ---------------------------------------------------------------------------------------------------- one GPU measurement
-def measure(pkg, torch, pdist, ctx, wl, spp, steps, warmup, world, rank, fb_t, rehearse):
+class _NoDist:
+    """Stand-in for webgpu_path_tracer_amd.dist when there is one process (no torch import at all: a fresh box pays 1-2 minutes for it)."""
+    TILE_PIXELS = 4096
+
+    @staticmethod
+    def barrier():
+        pass
+
+    @staticmethod
+    def all_reduce_scalar(value, op="sum"):
+        return value
+
+
+def measure(pkg, torch, pdist, ctx, wl, spp, steps, warmup, reduce_fn):
+    """reduce_fn: the step's collective (None on one GPU) — torch.distributed's reduce of the bound framebuffer tensor when the driver starts one
+    process per GPU, ptmi_reduce_framebuffer (ncclReduce inside the library) when one process drives all GPUs."""
     view = wl["view"]
 
     def step():
         ctx.clear()
         ctx.render(view, 1, spp)
         ctx.synchronize()
-        if world > 1 and rehearse:
-            host = fb_t.cpu()
-            pdist.reduce_framebuffer(host, 0)
-            fb_t.copy_(host)
-            torch.cuda.synchronize()
-        elif world > 1:
-            pdist.reduce_framebuffer(fb_t, 0)
-            torch.cuda.synchronize()  # the reduce runs on torch's stream; the next clear runs on the context's
+        if reduce_fn is not None:
+            reduce_fn()
 
     for _ in range(warmup):
         step()
@@ -376,6 +386,8 @@ def main():
     ap.add_argument("--bvh", default="median", choices=["median", "sah"],
                     help="median = the reference's live builder (default, what the metric is quoted on); sah = the reference's "
                          "other, never-called builder (lib/BVH/bvhNode.js:108-283) as an opt-in (not for c2's golden buffers)")
+    ap.add_argument("--devices", default="", help="comma-separated GPU ids for ONE multi-device context in this process (ptmi_create_multi + ncclReduce inside the library); "
+                                                 "implied by --gpus N > 1 without torch.distributed.run (then 0..N-1); `0,0` rehearses the path on one GPU")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N>1 on ONE GPU for rehearsal: ranks share cuda:0, the framebuffer reduce goes through gloo on host copies "
                          "(RCCL wants one device per rank); numbers from this mode are not bench results")
@@ -392,7 +404,15 @@ def main():
         return
 
     rank_env, world_env = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    solo = world_env == 1 and max(args.gpus, 1) == 1
+    # Three ways to run.  (a) one GPU.  (b) N > 1 under torch.distributed.run (WORLD_SIZE set: how the driver launches it): one process per GPU,
+    # torch.distributed's reduce over RCCL.  (c) N > 1 WITHOUT a launcher (`python bench.py --gpus N`, or --devices): ONE process, ONE context over
+    # the N GPUs (ptmi_create_multi: a host thread and a stream per GPU, pixel tiles dealt to them) and ncclReduce inside the library — the design
+    # north_star describes for the Node host.  `--devices 0,0` rehearses (c) on a one-GPU box (the shards share the GPU, summed by a kernel).
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else None
+    inlib = world_env == 1 and (devices is not None or max(args.gpus, 1) > 1)
+    if inlib and devices is None:
+        devices = list(range(args.gpus))
+    solo = world_env == 1 and not inlib
     extra_c3 = solo and args.extra_configs == "auto" and args.workload == "c2"
 
     # rocprofv3 passes first: child processes, before this process has touched the GPU
@@ -403,29 +423,45 @@ def main():
             if why:
                 pmc_note[w] = why
 
-    import torch
-
     pkg = entry._load_pkg()
-    from webgpu_path_tracer_amd import dist as pdist
+    torch = None
+    if world_env > 1:
+        import torch
+        from webgpu_path_tracer_amd import dist as pdist
 
-    rank, world, local = pdist.init_process_group("gloo" if args.rehearse_gloo else None)
-    if args.rehearse_gloo:
-        local = 0
-    if world != max(args.gpus, 1):
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    torch.cuda.set_device(local)
+        rank, world, local = pdist.init_process_group("gloo" if args.rehearse_gloo else None)
+        if args.rehearse_gloo:
+            local = 0
+        if world != max(args.gpus, 1):
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+        torch.cuda.set_device(local)
+    else:
+        pdist, rank, local = _NoDist, 0, 0
+        world = len(devices) if inlib else 1
 
     def run_workload(name, steps, warmup, spp_arg):
         wl = make_workload(pkg, name, args)
         per = spp_arg or SPP[name]
         spp = per * world if args.scaling == "weak" else per
-        ctx = make_context(pkg, wl, local, args)
-        fb_t = None
-        if world > 1:
+        ctx = make_context(pkg, wl, devices if inlib else local, args)
+        reduce_fn = None
+        if inlib:
+            reduce_fn = ctx.reduce_framebuffer
+        elif world > 1:
             fb_t = torch.zeros(wl["H"] * wl["W"] * 4, dtype=torch.float32, device="cuda")
             ctx.bind_framebuffer(fb_t.data_ptr(), fb_t.numel() * 4)
             ctx.set_shard(rank, world, pdist.TILE_PIXELS)
-        m = measure(pkg, torch, pdist, ctx, wl, spp, steps, warmup, world, rank, fb_t, args.rehearse_gloo)
+
+            def reduce_fn():
+                if args.rehearse_gloo:
+                    host = fb_t.cpu()
+                    pdist.reduce_framebuffer(host, 0)
+                    fb_t.copy_(host)
+                else:
+                    pdist.reduce_framebuffer(fb_t, 0)
+                torch.cuda.synchronize()  # the reduce runs on torch's stream; the next clear runs on the context's
+
+        m = measure(pkg, torch, pdist, ctx, wl, spp, steps, warmup, reduce_fn)
         return wl, ctx, spp, per, m
 
     wl, ctx, spp, per, m = run_workload(args.workload, args.steps, args.warmup, args.spp)
@@ -472,7 +508,9 @@ def main():
                 "workload": d["workload"],
                 "rays_per_step": d["rays_per_step"],
                 "mpaths_per_s": d["mpaths_per_s"],
-                "parallelism": ("pixel tiles x%d + 1 RCCL reduce" % world) if world > 1 else "1 GPU",
+                "parallelism": ("ptmi_create_multi x%d (one process, one context; devices %s) + 1 ncclReduce inside the library%s" % (
+                    world, ",".join(map(str, devices)), "" if len(set(devices)) == len(devices) else "; REHEARSAL: shards share a GPU, summed by a kernel") if inlib
+                    else ("pixel tiles x%d (one process per GPU) + 1 RCCL reduce (torch.distributed)" % world) if world > 1 else "1 GPU"),
             },
             "roofline": d["roofline"],
         }
@@ -530,8 +568,8 @@ def main():
                 wl3["setup"]["bvh_build_js_single_thread"] = js_bvh_build(wl3["native"])
             d3["setup_ms"] = wl3["setup"]
             out["configs"] = [d3]
-            out["vs_baseline"] = d3["vs_baseline"]
-            out["vs_baseline_basis"] = "configs[0] of this line (the dragon-class run): " + d3["vs_baseline_basis"]
+            # top-level vs_baseline stays null: BASELINE.md publishes no Mrays/s for configs[1]; the dragon ratio belongs to the configs[2] run above
+            out["vs_baseline_note"] = "no published number for this metric/config (BASELINE.json `published` is empty); the ratio to the reference's own dragon figure is in configs[0].vs_baseline"
         out["setup_ms"] = setup[args.workload]
         if args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(pkg, wl, spp, args)
@@ -541,7 +579,7 @@ def main():
                 out["cpu_baseline"]["bvh_build_js_ms"] = js_bvh_build(wl["native"])
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world_env > 1:
         import torch.distributed as dist
 
         dist.barrier()

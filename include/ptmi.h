@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PTMI_API_VERSION 2
+#define PTMI_API_VERSION 3
 
 typedef struct ptmi_ctx ptmi_ctx;
 
@@ -63,7 +63,11 @@ typedef struct ptmi_params {
   float fov_degrees;           /* 60                                                          */
   int32_t frames_in_flight;    /* ptmi_render batches this many frames per wavefront pass; 0 = auto: a 2^29-path budget
                                 * (256 frames at 1080p, ~80 GB of path state; PTMI_PATH_BUDGET_LOG2 overrides) */
-  int32_t reserved[5];
+  float tmin;                  /* ray_tmin = 0.000001 (header.wgsl:37): lower end of every t interval and the triangle test's epsilon;
+                                * >= 0 and finite                                             */
+  float light_mix;             /* 0.2: probability of following the light sample and its weight in the mixture pdf, the surface
+                                * sample gets 1 - light_mix = the shader's 0.8 (traceRay.wgsl:43,49); in [0,1]; importance sampling only */
+  int32_t reserved[3];
 } ptmi_params;
 
 /* Exact work counters (device-side when ptmi_set_counters(ctx,1); `rays` and `paths` always) and
@@ -164,6 +168,11 @@ int ptmi_prepare(ptmi_ctx* ctx);
  * read/write synchronise the stream; bytes must be W*H*16. */
 int ptmi_read_framebuffer(ptmi_ctx* ctx, float* rgba_sum, size_t bytes);
 int ptmi_write_framebuffer(ptmi_ctx* ctx, const float* rgba_sum, size_t bytes);
+/* The one collective of a multi-device render on its own (renderer.js has no counterpart: one GPU): waits for every device, then sums
+ * the per-device accumulation buffers into the gather buffer on device_ids[0] — ncclReduce over xGMI, see ptmi_create_multi — without
+ * copying anything to the host.  ptmi_read_framebuffer / ptmi_resolve_rgba8 do this themselves; bench.py times it as part of a step.
+ * On a single-device context it only synchronises. */
+int ptmi_reduce_framebuffer(ptmi_ctx* ctx);
 /* Device pointer of the accumulation buffer (for an in-place RCCL reduce by the host program). */
 int ptmi_framebuffer_device_ptr(ptmi_ctx* ctx, void** dev_ptr, size_t* bytes);
 /* Use caller-owned device memory (>= W*H*16 bytes, 16-byte aligned) as the accumulation buffer. */

@@ -142,6 +142,8 @@ struct ptmo_params {
   int32_t stack_size;           // STACK_SIZE   header.wgsl:13
   float background[3];          // traceRay.wgsl:8
   float fov_factor;             // main.wgsl:7, folded in f64 by the caller
+  float ray_tmin;               // ray_tmin, header.wgsl:37 (0.000001)
+  float light_mix;              // probability / weight of the light sample, traceRay.wgsl:43,49 (0.2; the surface gets 1 - light_mix = the shader's 0.8)
 };
 struct ptmo_stats {
   uint64_t rays;          // hitScene invocations
@@ -192,6 +194,7 @@ struct Thread {
     pixelCoords = unit_w = u = v = cam_origin = V(0, 0, 0);
     memset(stack, 0, sizeof stack);
     fovFactor = p_->fov_factor;
+    ray_tmin = p_->ray_tmin;
   }
 
   Material load_material(int i) {
@@ -592,10 +595,10 @@ struct Thread {
         Ray scattered_light = get_random_on_quad(lights, hitRec.p);
         Ray scattered = scattered_light;
         float rnd = rand2D();
-        if (rnd > 0.2f) scattered = scatterred_surface;
+        if (rnd > prm->light_mix) scattered = scatterred_surface;
         float lambertian_pdf = onb_lambertian_scattering_pdf(scattered);
         float lpdf = light_pdf(scattered, lights);
-        float pdf = 0.2f * lpdf + 0.8f * lambertian_pdf;
+        float pdf = prm->light_mix * lpdf + (1.0f - prm->light_mix) * lambertian_pdf;  // 1.0f - 0.2f == 0.8f
         if (pdf <= 0.00001f) return emissionColor * throughput;  // drops acc (Q8)
         acc_radiance = acc_radiance + emissionColor * throughput;
         throughput = throughput * ((lambertian_pdf * mix(hitRec.material.color, hitRec.material.specularColor, doSpecular)) / pdf);

@@ -23,7 +23,7 @@ class _Scene(ctypes.Structure):
 class _Params(ctypes.Structure):
     _fields_ = [("num_samples", ctypes.c_int32), ("max_bounces", ctypes.c_int32), ("stratify", ctypes.c_int32),
                 ("importance_sampling", ctypes.c_int32), ("stack_size", ctypes.c_int32), ("background", ctypes.c_float * 3),
-                ("fov_factor", ctypes.c_float)]
+                ("fov_factor", ctypes.c_float), ("ray_tmin", ctypes.c_float), ("light_mix", ctypes.c_float)]
 
 
 class _Stats(ctypes.Structure):
@@ -71,12 +71,14 @@ def _scene(buffers, keep):
     return s
 
 
-def _params(num_samples=1, max_bounces=100, stratify=0, importance_sampling=0, stack_size=20, background=(0.0, 1.0, 1.0), fov_degrees=60.0):
+def _params(num_samples=1, max_bounces=100, stratify=0, importance_sampling=0, stack_size=20, background=(0.0, 1.0, 1.0), fov_degrees=60.0,
+            tmin=0.000001, light_mix=0.2):
     p = _Params()
     p.num_samples, p.max_bounces, p.stratify = num_samples, max_bounces, int(stratify)
     p.importance_sampling, p.stack_size = int(importance_sampling), stack_size
     p.background[:] = list(background)
     p.fov_factor = float(fov_factor(fov_degrees))
+    p.ray_tmin, p.light_mix = float(np.float32(tmin)), float(np.float32(light_mix))
     return p
 
 

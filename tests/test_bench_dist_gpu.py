@@ -61,3 +61,32 @@ def test_bench_line_contract_with_its_own_pmc_passes():
             assert 0 <= v["valu_busy_frac"] <= 1 and 0 <= v["hbm_frac"] <= 1 and 0 < v["active_lane_frac"] <= 1
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["single_thread"]["cores"] == 1 and cb["single_thread"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_in_library_multi_device_path_without_a_launcher():
+    """`python bench.py --gpus N` with no torch.distributed.run around it: ONE process, ONE context over the N GPUs (ptmi_create_multi), the reduce
+    inside the library (ptmi_reduce_framebuffer).  Rehearsed on one GPU with --devices 0,0 (the shards share the GPU and are summed by a kernel)."""
+    common = ["--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--pmc", "off", "--extra-configs", "off", "--width", "320", "--height", "180", "--spp", "4"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    one = subprocess.run([sys.executable, "bench.py"] + common, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    a = json.loads(one.stdout.strip().splitlines()[-1])
+    two = subprocess.run([sys.executable, "bench.py", "--devices", "0,0", "--scaling", "strong"] + common, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    lines = [l for l in two.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["scaling"] == "strong" and b["metric"] == a["metric"] and b["value"] > 0
+    assert "ptmi_create_multi x2" in b["config"]["parallelism"] and "ncclReduce" in b["config"]["parallelism"]
+    assert b["config"]["rays_per_step"] == a["config"]["rays_per_step"]  # the same 4 frames, pixel tiles dealt to the two shards
+    # weak scaling (the default): spp x 2
+    w = subprocess.run([sys.executable, "bench.py", "--devices", "0,0"] + common, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert w.returncode == 0, w.stderr[-2000:]
+    c = json.loads([l for l in w.stdout.strip().splitlines() if l.startswith("{")][0])
+    assert c["scaling"] == "weak" and 1.8 < c["config"]["rays_per_step"] / a["config"]["rays_per_step"] < 2.2
+    # asking for more GPUs than the box has fails loudly (the driver must see it), it does not fall back to one
+    bad = subprocess.run([sys.executable, "bench.py", "--gpus", "64"] + common, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert bad.returncode != 0

@@ -36,6 +36,9 @@ CASES = [
     ("c2", "oblique", 128, 72, 2, dict(max_bounces=8, stack_size=4)),  # Q7 abort active
     ("c2", "cornell", 64, 48, 1, dict(max_bounces=0)),
     ("c2", "cornell", 100, 37, 2, dict(max_bounces=3, background=(0.3, 0.2, 0.9), fov_degrees=75.0)),  # W*H not a multiple of 64
+    # ray_tmin (header.wgsl:37) and the light / surface mixture (traceRay.wgsl:43,49) away from the reference's 1e-6 and 0.2 / 0.8
+    ("c2m", "cornell", 128, 96, 2, dict(max_bounces=8, importance_sampling=1, tmin=0.002, light_mix=0.45)),
+    ("default", "default", 120, 80, 2, dict(max_bounces=10, tmin=0.01)),
 ]
 
 
@@ -245,6 +248,25 @@ def test_resolve_rgba8(ctx, pkg, oracle):
         assert np.array_equal(ctx.resolve_rgba8(frame_num), oracle.resolve_rgba8(sweep, frame_num)), frame_num
 
 
+def _full_size_windows(ctx, oracle, b, view, W, H, frames, params, label):
+    """The scene at a BASELINE configuration's FULL resolution against the oracle on 6000-pixel windows of the image: one across the
+    middle (through the mesh), one in the last rows (the largest pixel indices: `f32(pixelIndex) % W`, `/ W` of main.wgsl:3-5, Q1,
+    and the largest path ids), one at the very start.  The whole frame is rendered (frames_in_flight auto); counters are not compared
+    (the oracle sees only the windows)."""
+    ctx.set_params(**params)
+    ctx.resize(W, H)
+    ctx.reset_stats()
+    ctx.render(view, 1, frames)
+    got = ctx.read_framebuffer().reshape(-1, 4)
+    st = ctx.stats()
+    assert st["paths"] == W * H * frames and st["frames"] == frames
+    assert (got[:, 3] == 1.0).all()
+    for p0 in ((H // 2) * W + W // 3, W * H - 6000, 0):
+        want, _ = oracle.render(b, W, H, view, 1, frames, pixel_range=(p0, p0 + 6000), **_oracle_params(params))
+        assert_same_bits(got[p0 : p0 + 6000], want.reshape(-1, 4)[p0 : p0 + 6000], "%s %dx%d window at pixel %d" % (label, W, H, p0))
+    ctx.resize(64, 64)  # give the frame-sized buffers back
+
+
 def test_dragon_class_scene_bit_exact(ctx, pkg, oracle):
     """BASELINE configs[2] geometry (871,414 triangles, BVH depth 20, stack_size 24) at reduced resolution."""
     b = pkg.scenes.c3_scene().buffers(native=pkg.ptmi.NativeHost())
@@ -264,6 +286,8 @@ def test_dragon_class_scene_bit_exact(ctx, pkg, oracle):
         assert_same_bits(got, want, "c3 stack %d" % stack)
         for k in ("rays", "node_visits", "tri_tests", "quad_tests", "mat_fetches"):
             assert st[k] == ost[k], (stack, k)
+    # configs[2] at its own size: 1920x1080, stack_size 24
+    _full_size_windows(ctx, oracle, b, view, 1920, 1080, 3, dict(max_bounces=8, stack_size=24), "configs[2]")
 
 
 @pytest.mark.parametrize("name,cam,params", [
@@ -287,6 +311,9 @@ def test_large_procedural_scenes_bit_exact(ctx, pkg, oracle, name, cam, params):
     assert_same_bits(got, want, name)
     for k in ("rays", "node_visits", "tri_tests", "quad_tests", "mat_fetches"):
         assert st[k] == ost[k], (name, k)
+    # configs[3] at 1920x1080, configs[4] at 3840x2160 (8.3 M pixels: pixel indices beyond 2^23, 16 bounces, importance sampling)
+    W, H = (3840, 2160) if name == "c5" else (1920, 1080)
+    _full_size_windows(ctx, oracle, b, view, W, H, 3 if name == "c5" else 2, params, "configs[%d]" % (4 if name == "c5" else 3))
 
 
 def _collapse_bottom_level(bvh, n_tris):
@@ -388,6 +415,8 @@ def test_sah_bvh_bit_exact(ctx, pkg, oracle):
         assert_same_bits(got, want, "sah stack %d" % stack)
         for k in ("rays", "node_visits", "tri_tests", "quad_tests", "mat_fetches"):
             assert st[k] == ost[k], (stack, k)
+    # configs[2] at its own size: 1920x1080, stack_size 24
+    _full_size_windows(ctx, oracle, b, view, 1920, 1080, 3, dict(max_bounces=8, stack_size=24), "configs[2]")
 
 
 def _random_scene(pkg, seed):
@@ -544,3 +573,29 @@ def test_auto_batch_shrinks_when_memory_is_short(pkg, oracle, monkeypatch):
             ctx.render(view, 1, 512)
     want, _ = oracle.render(b, 256, 256, view, 1, 512, max_bounces=3, pixel_range=(256 * 100, 256 * 100 + 512), threads=8)  # 512 pixels: few threads
     assert_same_bits(got.reshape(-1, 4)[256 * 100:256 * 100 + 512], want.reshape(-1, 4)[256 * 100:256 * 100 + 512], "two rows of the 512-frame image")
+
+
+def test_failed_triangle_reupload_keeps_the_old_scene(pkg, oracle, monkeypatch):
+    """ptmi_upload(TRIANGLES) allocates before it lets go of anything: when the board cannot hold a larger mesh the call fails and the
+    context — every device of a multi-device one — keeps rendering the scene it had (never a freed buffer)."""
+    b = pkg.scenes.golden_buffers("c2")
+    view = cornell_view(pkg)
+    big = np.tile(np.asarray(b["triangles"], np.float32).reshape(-1, 24), (24, 1))  # 2.2 MB of triangles
+    for devices in (0, [0, 0]):
+        with pkg.Context(devices) as ctx:
+            ctx.upload_scene(b)
+            ctx.set_params(max_bounces=4)
+            ctx.resize(96, 64)
+            ctx.render(view, 1, 2)
+            before = ctx.read_framebuffer()
+            monkeypatch.setenv("PTMI_TEST_ALLOC_LIMIT", str(1 << 20))
+            with pytest.raises(pkg.PtmiError):
+                ctx.upload("triangles", big)
+            monkeypatch.delenv("PTMI_TEST_ALLOC_LIMIT")
+            ctx.clear()
+            ctx.render(view, 1, 2)
+            assert_same_bits(ctx.read_framebuffer(), before, "after the failed upload")
+            ctx.upload("triangles", np.asarray(b["triangles"], np.float32))  # a same-size upload reuses the buffer
+            ctx.clear()
+            ctx.render(view, 1, 2)
+            assert_same_bits(ctx.read_framebuffer(), before, "after re-uploading the same triangles")

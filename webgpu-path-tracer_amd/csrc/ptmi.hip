@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -428,6 +429,7 @@ int prepare_scene(ptmi_ctx* c) {
   S.root_hi = make_float4(root_hi[0], root_hi[1], root_hi[2], root_hi[3]);
   S.n_spheres = n_sph, S.n_quads = n_quad, S.n_tris = n_tri, S.n_meshes = n_mesh, S.n_xforms = n_xf, S.n_mats = n_mat, S.n_nodes = n_node;
   S.light_quad = light;
+  S.tmin = c->prm.tmin;
   c->scene_dirty = false;
   return PTMI_OK;
 }
@@ -602,6 +604,8 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
     rc.sample_div = (float)p.num_samples;
   }
   rc.stack_size = p.stack_size;
+  rc.light_mix = p.light_mix;
+  rc.surface_mix = 1.0f - p.light_mix;  // 1.0f - 0.2f == 0.8f, the shader's literal
   rc.npix = (uint32_t)c->W * (uint32_t)c->H;
   rc.frame0 = frame0;
   rc.n_frames = n_frames;
@@ -764,6 +768,11 @@ struct Rccl {
   }
 };
 Rccl g_rccl;
+std::once_flag g_rccl_once;  // two host threads may create multi-device contexts at the same time
+bool rccl_loaded() {
+  std::call_once(g_rccl_once, [] { (void)g_rccl.load(); });
+  return g_rccl.lib != nullptr;
+}
 
 #define RCCL_TRY(c, expr)                                                                                            \
   do {                                                                                                               \
@@ -786,7 +795,7 @@ int on_all_devices(ptmi_ctx* c, F fn, bool parallel = false) {
     for (auto& t : th) t.join();
   } else {
     rcs[0] = fn(c);
-    for (size_t i = 0; i < n && !rcs[0]; i++) rcs[i + 1] = fn(c->peers[i]);
+    for (size_t i = 0; i < n && !rcs[i]; i++) rcs[i + 1] = fn(c->peers[i]);  // stop at the first device that fails
   }
   for (size_t i = 1; i <= n; i++)
     if (rcs[i] && !rcs[0]) {
@@ -822,14 +831,25 @@ int gather_framebuffer(ptmi_ctx* c, float4** out) {
   HIP_TRY(c, c->d_fb_gather.ensure(bytes));
   float4* g = c->d_fb_gather.as<float4>();
   if (c->use_rccl) {
-    // ncclReduce(sendbuff = this device's buffer, recvbuff = the gather buffer on the root, W*H*4 floats, sum, root 0)
+    // ncclReduce(sendbuff = this device's buffer, recvbuff = the gather buffer on the root, W*H*4 floats, sum, root 0).
+    // A group that has been started is always ended — an open group would swallow every later RCCL call of the process —;
+    // the first error inside it is reported after ncclGroupEnd.
     RCCL_TRY(c, g_rccl.GroupStart());
-    for (size_t i = 0; i <= c->peers.size(); i++) {
+    std::string first_error;
+    for (size_t i = 0; i <= c->peers.size() && first_error.empty(); i++) {
       ptmi_ctx* q = i ? c->peers[i - 1] : c;
-      HIP_TRY(c, hipSetDevice(q->device));
-      RCCL_TRY(c, g_rccl.Reduce(q->fb, i ? (void*)q->fb : (void*)g, n4 * 4, ncclFloat, ncclSum, 0, c->comms[i], q->stream));
+      const hipError_t he = hipSetDevice(q->device);
+      if (he != hipSuccess) {
+        first_error = std::string("hipSetDevice: ") + hipGetErrorString(he);
+        break;
+      }
+      const ncclResult_t nr = g_rccl.Reduce(q->fb, i ? (void*)q->fb : (void*)g, n4 * 4, ncclFloat, ncclSum, 0, c->comms[i], q->stream);
+      if (nr != ncclSuccess) first_error = std::string("ncclReduce (local device #") + std::to_string(i) + "): " + g_rccl.GetErrorString(nr);
     }
-    RCCL_TRY(c, g_rccl.GroupEnd());
+    const ncclResult_t ge = g_rccl.GroupEnd();
+    (void)hipSetDevice(c->device);
+    if (!first_error.empty()) return fail(c, PTMI_ERR_DEVICE, first_error);
+    if (ge != ncclSuccess) return fail(c, PTMI_ERR_DEVICE, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(ge));
     for (size_t i = 0; i <= c->peers.size(); i++) {
       ptmi_ctx* q = i ? c->peers[i - 1] : c;
       HIP_TRY(c, hipSetDevice(q->device));
@@ -913,6 +933,8 @@ void ptmi_default_params(ptmi_params* p) {
   p->background[0] = 0.0f, p->background[1] = 1.0f, p->background[2] = 1.0f;
   p->fov_degrees = 60.0f;
   p->frames_in_flight = 0;
+  p->tmin = 0.000001f;   // header.wgsl:37
+  p->light_mix = 0.2f;   // traceRay.wgsl:43,49
 }
 
 int ptmi_create(ptmi_ctx** out, int device_id) {
@@ -971,7 +993,7 @@ int ptmi_create_multi(ptmi_ctx** out, const int* device_ids, int n_devices) {
     return fail(nullptr, PTMI_ERR_UNSUPPORTED, "PTMI_MULTI_REDUCE=rccl needs distinct device ids (an RCCL communicator cannot hold a GPU twice)");
   }
   if (c->use_rccl) {
-    if (!g_rccl.load()) {
+    if (!rccl_loaded()) {
       ptmi_destroy(c);
       return fail(nullptr, PTMI_ERR_DEVICE, "ptmi_create_multi: cannot load librccl (" + g_rccl.why + "); set PTMI_RCCL_LIB, or PTMI_MULTI_REDUCE=copy for peer copies instead");
     }
@@ -1023,10 +1045,14 @@ int ptmi_set_params(ptmi_ctx* c, const ptmi_params* p) {
   if ((int64_t)p->num_samples * p->max_bounces > 65536)
     return fail(c, PTMI_ERR_UNSUPPORTED, "ptmi_set_params: num_samples * max_bounces > 65536");
   if (!(p->fov_degrees > 0.0f && p->fov_degrees < 180.0f)) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_set_params: fov_degrees must be in (0,180)");
+  if (!(p->tmin >= 0.0f && p->tmin < 3.0e38f)) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_set_params: tmin must be finite and >= 0 (the reference: 0.000001)");
+  if (!(p->light_mix >= 0.0f && p->light_mix <= 1.0f)) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_set_params: light_mix must be in [0,1] (the reference: 0.2)");
   c->prm = *p;
+  c->S.tmin = p->tmin;  // (the kernels take it with the scene; prepare_scene sets it too)
   c->ahead.valid = false;
   for (ptmi_ctx* q : c->peers) {
     q->prm = *p;
+    q->S.tmin = p->tmin;
     q->ahead.valid = false;
   }
   return PTMI_OK;
@@ -1038,24 +1064,41 @@ int ptmi_get_params(const ptmi_ctx* c, ptmi_params* p) {
   return PTMI_OK;
 }
 
-int ptmi_upload(ptmi_ctx* c, int which, const void* data, size_t bytes) {
-  if (!c) return PTMI_ERR_INVALID_ARG;
-  size_t stride = stride_of(which);
-  if (!stride) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_upload: unknown buffer id");
-  if (bytes % stride) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_upload: byte size is not a multiple of the buffer's stride");
-  if (bytes && !data) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_upload: data is null");
-  if (bytes / stride > 0x0fffffffull) return fail(c, PTMI_ERR_UNSUPPORTED, "ptmi_upload: more than 2^28-1 elements");
+// One device's share of ptmi_upload.  The triangles (the largest buffer: 84 MB at 871 k triangles) go straight from the caller's memory to
+// the device — no host copy — in two steps, so that a failure leaves every device of a multi-device context with the scene it had:
+// upload_stage allocates what the new array needs WITHOUT touching the old one; upload_commit copies and swaps.
+static int upload_stage(ptmi_ctx* c, int which, size_t bytes, DBuf* fresh) {
+  if (which != PTMI_BUF_TRIANGLES || bytes <= c->d_tris.cap) return PTMI_OK;  // fits what is there: nothing to allocate
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, fresh->ensure(std::max<size_t>(bytes, 16)));
+  return PTMI_OK;
+}
+static int upload_commit(ptmi_ctx* c, int which, const void* data, size_t bytes, DBuf* fresh) {
   const float* f = (const float*)data;
   switch (which) {
     case PTMI_BUF_SPHERES: c->h_spheres.assign(f, f + bytes / 4); break;
     case PTMI_BUF_QUADS: c->h_quads.assign(f, f + bytes / 4); break;
-    case PTMI_BUF_TRIANGLES:  // the largest buffer (84 MB at 871 k triangles): no host copy, one synchronous transfer from the caller's memory
-      HIP_TRY(c, hipSetDevice(c->device));
-      HIP_TRY(c, hipStreamSynchronize(c->stream));  // nothing in flight may still read the old triangles
-      HIP_TRY(c, c->d_tris.ensure(std::max<size_t>(bytes, 16)));
-      if (bytes) HIP_TRY(c, hipMemcpy(c->d_tris.p, data, bytes, hipMemcpyHostToDevice));
+    case PTMI_BUF_TRIANGLES: {
+      hipError_t e = hipSetDevice(c->device);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // nothing in flight may still read the old triangles
+      if (e == hipSuccess && fresh->p) {
+        c->d_tris.release();
+        c->d_tris = *fresh;
+        *fresh = DBuf();
+      }
+      if (e == hipSuccess && bytes) e = hipMemcpy(c->d_tris.p, data, bytes, hipMemcpyHostToDevice);
+      if (e != hipSuccess) {
+        // the device no longer holds a valid triangle array: make the context say so instead of tracing stale or freed memory
+        c->n_tris_uploaded = 0;
+        c->S.tris = nullptr;
+        c->S.n_tris = 0;
+        c->scene_dirty = true;
+        c->ahead.valid = false;
+        return fail(c, PTMI_ERR_DEVICE, std::string("ptmi_upload(triangles): ") + hipGetErrorString(e) + " — the triangle buffer is now empty; upload it again");
+      }
       c->n_tris_uploaded = bytes / 96;
       break;
+    }
     case PTMI_BUF_MESHES: c->h_meshes.assign((const int32_t*)data, (const int32_t*)data + bytes / 4); break;
     case PTMI_BUF_TRANSFORMS: c->h_xforms.assign(f, f + bytes / 4); break;
     case PTMI_BUF_MATERIALS: c->h_mats.assign(f, f + bytes / 4); break;
@@ -1063,11 +1106,40 @@ int ptmi_upload(ptmi_ctx* c, int which, const void* data, size_t bytes) {
   }
   c->scene_dirty = true;
   c->ahead.valid = false;
-  for (ptmi_ctx* q : c->peers) {  // the scene is replicated on every device
-    int r = ptmi_upload(q, which, data, bytes);
-    if (r) return fail(c, r, q->err);
-  }
   return PTMI_OK;
+}
+
+int ptmi_upload(ptmi_ctx* c, int which, const void* data, size_t bytes) {
+  if (!c) return PTMI_ERR_INVALID_ARG;
+  size_t stride = stride_of(which);
+  if (!stride) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_upload: unknown buffer id");
+  if (bytes % stride) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_upload: byte size is not a multiple of the buffer's stride");
+  if (bytes && !data) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_upload: data is null");
+  if (bytes / stride > 0x0fffffffull) return fail(c, PTMI_ERR_UNSUPPORTED, "ptmi_upload: more than 2^28-1 elements");
+  // the scene is replicated on every device of a multi-device context: stage everywhere first, commit only when every device can take it
+  const size_t n = c->peers.size() + 1;
+  std::vector<DBuf> fresh(n);
+  for (size_t i = 0; i < n; i++) {
+    ptmi_ctx* q = i ? c->peers[i - 1] : c;
+    const int r = upload_stage(q, which, bytes, &fresh[i]);
+    if (r) {
+      for (size_t k = 0; k <= i; k++) {
+        (void)hipSetDevice((k ? c->peers[k - 1] : c)->device);
+        fresh[k].release();
+      }
+      (void)hipSetDevice(c->device);
+      return i ? fail(c, r, "local device #" + std::to_string(i) + ": " + q->err + " (no device was changed)") : r;
+    }
+  }
+  int rc = PTMI_OK;
+  for (size_t i = 0; i < n; i++) {
+    ptmi_ctx* q = i ? c->peers[i - 1] : c;
+    const int r = upload_commit(q, which, data, bytes, &fresh[i]);
+    if (r && !rc) rc = i ? fail(c, r, "local device #" + std::to_string(i) + ": " + q->err) : r;
+  }
+  for (size_t k = 0; k < n; k++) fresh[k].release();  // (only after a device error during the commit)
+  (void)hipSetDevice(c->device);
+  return rc;
 }
 
 int ptmi_resize(ptmi_ctx* c, int width, int height) {
@@ -1245,6 +1317,17 @@ int ptmi_read_framebuffer(ptmi_ctx* c, float* dst, size_t bytes) {
     drain_spans(q);
     return check_queue_overflow(q);
   });
+}
+
+int ptmi_reduce_framebuffer(ptmi_ctx* c) {
+  if (!c) return PTMI_ERR_INVALID_ARG;
+  if (!c->fb) return fail(c, PTMI_ERR_STATE, "ptmi_reduce_framebuffer: no framebuffer");
+  HIP_TRY(c, hipSetDevice(c->device));
+  float4* src = nullptr;
+  int r = gather_framebuffer(c, &src);
+  if (r) return r;
+  if (!c->multi) HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return PTMI_OK;
 }
 
 int ptmi_write_framebuffer(ptmi_ctx* c, const float* src, size_t bytes) {

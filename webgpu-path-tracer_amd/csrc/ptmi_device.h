@@ -21,7 +21,6 @@ constexpr float kTwoPi = 2.0 * 3.14159265358979323846;
 constexpr float kMinFloat = 0.0001;
 constexpr float kMaxFloat = 999999999.999;        // 1.0e9f
 constexpr float kMaxFloatP1 = 999999999.999 + 1;  // also 1.0e9f: f32 ulp there is 64
-constexpr float kTmin = 0.000001;
 
 // hit kinds (upper 4 bits of the packed primitive word)
 enum : uint32_t { K_NONE = 0, K_SPHERE = 1, K_VOLUME = 2, K_QUAD = 3, K_TRI = 4 };
@@ -191,6 +190,7 @@ struct DevScene {
   float4 root_lo, root_hi;  // root box; root_lo.w = root's child ref
   int n_spheres, n_quads, n_tris, n_meshes, n_xforms, n_mats, n_nodes;
   int light_quad;  // first quad with emission.x > 0 (common.wgsl:258-269), -1 if none
+  float tmin;      // ray_tmin (header.wgsl:37; ptmi_params.tmin, 0.000001 by default)
 };
 
 // ---- path state ----------------------------------------------------------------------------------------
@@ -246,6 +246,7 @@ struct RenderConst {
   float recip_sqrt_spp;
   float sample_div;   // divisor of pixColor (NUM_SAMPLES or numSamples)
   int stack_size;
+  float light_mix, surface_mix;  // traceRay.wgsl:43,49: 0.2 and 1 - 0.2 = 0.8 (ptmi_params.light_mix)
   uint32_t npix;
   uint32_t frame0;
   int n_frames;
@@ -346,7 +347,7 @@ DEV void hit_spheres(const DevScene& S, f3 o, f3 d, uint32_t& rng, Closest& c, C
     if (COUNT) cn.sphere_tests++;
     if (!info.y) {
       float root;
-      if (sphere_root(center, r, kTmin, c.t, o, d, root)) {
+      if (sphere_root(center, r, S.tmin, c.t, o, d, root)) {
         c.t = root;
         c.prim = (K_SPHERE << 28) | (uint32_t)i;
         c.mat = info.x;
@@ -356,7 +357,7 @@ DEV void hit_spheres(const DevScene& S, f3 o, f3 d, uint32_t& rng, Closest& c, C
       float rec1, rec2;
       if (!sphere_root(center, r, -kMaxFloat, kMaxFloat, o, d, rec1)) continue;  // == MAX_FLOAT + 1 sentinel
       if (!sphere_root(center, r, rec1 + 0.0001f, kMaxFloat, o, d, rec2)) continue;
-      if (rec1 < kTmin) rec1 = kTmin;
+      if (rec1 < S.tmin) rec1 = S.tmin;
       if (rec2 > c.t) rec2 = c.t;
       if (rec1 >= rec2) continue;
       if (rec1 < 0) rec1 = 0;
@@ -387,7 +388,7 @@ DEV void hit_quads(const DevScene& S, f3 o, f3 d, Closest& c, Counters& cn) {
     float denom = dot3(n, d);
     if (ptm_abs(denom) < 1e-8f) continue;
     float t = (q3.w - dot3(n, o)) / denom;
-    if (t <= kTmin || t >= c.t) continue;
+    if (t <= S.tmin || t >= c.t) continue;
     f3 isect = o + t * d;
     f3 ph = isect - mk3(q0);
     f3 w = mk3(q4);
@@ -402,12 +403,12 @@ DEV void hit_quads(const DevScene& S, f3 o, f3 d, Closest& c, Counters& cn) {
 }
 
 // shaders/common.wgsl:245-256
-DEV bool hit_aabb(float4 lo, float4 hi, float tmax, f3 o, f3 inv) {
+DEV bool hit_aabb(float4 lo, float4 hi, float tmin, float tmax, f3 o, f3 inv) {
   float t0x = (lo.x - o.x) * inv.x, t0y = (lo.y - o.y) * inv.y, t0z = (lo.z - o.z) * inv.z;
   float t1x = (hi.x - o.x) * inv.x, t1y = (hi.y - o.y) * inv.y, t1z = (hi.z - o.z) * inv.z;
   float sx = ptm_min(t0x, t1x), sy = ptm_min(t0y, t1y), sz = ptm_min(t0z, t1z);
   float bx = ptm_max(t0x, t1x), by = ptm_max(t0y, t1y), bz = ptm_max(t0z, t1z);
-  float t_min = ptm_max(kTmin, ptm_max(sx, ptm_max(sy, sz)));
+  float t_min = ptm_max(tmin, ptm_max(sx, ptm_max(sy, sz)));
   float t_max = ptm_min(tmax, ptm_min(bx, ptm_min(by, bz)));
   return t_max > t_min;
 }
@@ -427,7 +428,7 @@ DEV void prims_for_ray(const DevScene& S, f3 o, f3 d, uint32_t& rng, float2& tp,
   if (S.n_nodes > 0) {
     if (COUNT) cn.node_visits++;
     const f3 inv = rcp3_exact(d);  // 1 / ray.dir (hitRay.wgsl:46)
-    to_bvh = hit_aabb(S.root_lo, S.root_hi, c.t, o, inv);
+    to_bvh = hit_aabb(S.root_lo, S.root_hi, S.tmin, c.t, o, inv);
   }
   tp = make_float2(c.t, __uint_as_float(c.prim));
   hitmat = (((c.prim >> 28) != K_NONE) ? (uint32_t)c.mat : HITMAT_MISS) | (to_bvh ? HITMAT_BVH : 0u);
@@ -458,7 +459,7 @@ DEV void hit_triangle(const DevScene& S, int k, f3 o, f3 d, ObjRay& orr, Closest
   if (COUNT) cn.tri_tests++;
   f3 A = mk3(t0), AB = mk3(t1), AC = mk3(t2), N = mk3(t3);
   float det = -dot3(orr.d, N);
-  if (ptm_abs(det) < kTmin) return;
+  if (ptm_abs(det) < S.tmin) return;
   f3 ao = orr.o - A;
   f3 dao = cross3(ao, orr.d);
   float invDet = rcp_exact_il(det);
@@ -466,7 +467,7 @@ DEV void hit_triangle(const DevScene& S, int k, f3 o, f3 d, ObjRay& orr, Closest
   float u = dot3(AC, dao) * invDet;
   float v = -dot3(AB, dao) * invDet;
   float w = 1.0f - u - v;
-  if (dst < kTmin || dst > c.t || u < kTmin || v < kTmin || w < kTmin) return;
+  if (dst < S.tmin || dst > c.t || u < S.tmin || v < S.tmin || w < S.tmin) return;
   c.t = dst;
   c.u = u;
   c.v = v;
@@ -477,12 +478,12 @@ DEV void hit_triangle(const DevScene& S, int k, f3 o, f3 d, ObjRay& orr, Closest
 
 // t-interval of a ray against one box, the closest-independent part of hit_aabb (common.wgsl:246-253):
 // ts = max(tmin, max3(tsmaller)), tb = min3(tbigger); the box passes iff min(closest, tb) > ts.
-DEV void slab(float4 lo, float4 hi, f3 o, f3 inv, float& ts, float& tb) {
+DEV void slab(float4 lo, float4 hi, f3 o, f3 inv, float tmin, float& ts, float& tb) {
   float t0x = (lo.x - o.x) * inv.x, t0y = (lo.y - o.y) * inv.y, t0z = (lo.z - o.z) * inv.z;
   float t1x = (hi.x - o.x) * inv.x, t1y = (hi.y - o.y) * inv.y, t1z = (hi.z - o.z) * inv.z;
   float sx = ptm_min(t0x, t1x), sy = ptm_min(t0y, t1y), sz = ptm_min(t0z, t1z);
   float bx = ptm_max(t0x, t1x), by = ptm_max(t0y, t1y), bz = ptm_max(t0z, t1z);
-  ts = ptm_max(kTmin, ptm_max(sx, ptm_max(sy, sz)));
+  ts = ptm_max(tmin, ptm_max(sx, ptm_max(sy, sz)));
   tb = ptm_min(bx, ptm_min(by, bz));
 }
 
@@ -560,7 +561,7 @@ DEV void tri_record_test(const DevScene& S, int k, float4 t0, float4 t1, float4 
   if (COUNT) cn.tri_tests++;
   f3 A = mk3(t0), AB = mk3(t1), AC = mk3(t2), N = mk3(t3);
   float det = -dot3(t.orr.d, N);
-  if (ptm_abs(det) < kTmin) return;
+  if (ptm_abs(det) < S.tmin) return;
   f3 ao = t.orr.o - A;
   f3 dao = cross3(ao, t.orr.d);
   float invDet = rcp_exact_il(det);
@@ -568,7 +569,7 @@ DEV void tri_record_test(const DevScene& S, int k, float4 t0, float4 t1, float4 
   float u = dot3(AC, dao) * invDet;
   float v = -dot3(AB, dao) * invDet;
   float w = 1.0f - u - v;
-  if (dst < kTmin || dst > t.c.t || u < kTmin || v < kTmin || w < kTmin) return;
+  if (dst < S.tmin || dst > t.c.t || u < S.tmin || v < S.tmin || w < S.tmin) return;
   t.c.t = dst;
   t.c.u = u;
   t.c.v = v;
@@ -624,8 +625,8 @@ DEV void trav_inner_phase(const DevScene& S, int stack_size, const LaneStack& st
   const float4* rec = S.pairs + 4 * (size_t)t.cur;
   const float4 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3v = rec[3];
   float tsL, tbL, tsR, tbR;
-  slab(f0, f1, t.o, t.inv, tsL, tbL);
-  slab(f2, f3v, t.o, t.inv, tsR, tbR);
+  slab(f0, f1, t.o, t.inv, S.tmin, tsL, tbL);
+  slab(f2, f3v, t.o, t.inv, S.tmin, tsR, tbR);
   const int axis = __float_as_int(f2.w);
   const bool neg = ((t.negmask >> axis) & 1u) != 0u;
   const uint32_t refL = __float_as_uint(f0.w), refR = __float_as_uint(f1.w);
@@ -701,11 +702,11 @@ DEV void stack2_read(const LaneStack2& k, int e, uint32_t& w0, float& w1) {
 // One reference visit of an inner node's near child (boxes in the fetched pair record), far child pushed: trav_inner_phase
 // without its fetch and without the pops.  Returns the lane's next state word.
 template <bool COUNT, bool NOABORT>
-DEV uint32_t inner_step2(float4 f0, float4 f1, float4 f2, float4 f3v, f3 o, f3 inv, uint32_t negmask, float ct, int stack_size, const LaneStack2& stk, int& sp,
-                         Counters& cn) {
+DEV uint32_t inner_step2(float4 f0, float4 f1, float4 f2, float4 f3v, f3 o, f3 inv, float tmin, uint32_t negmask, float ct, int stack_size, const LaneStack2& stk,
+                         int& sp, Counters& cn) {
   float tsL, tbL, tsR, tbR;
-  slab(f0, f1, o, inv, tsL, tbL);
-  slab(f2, f3v, o, inv, tsR, tbR);
+  slab(f0, f1, o, inv, tmin, tsL, tbL);
+  slab(f2, f3v, o, inv, tmin, tsR, tbR);
   const int axis = __float_as_int(f2.w);
   const bool neg = ((negmask >> axis) & 1u) != 0u;
   const uint32_t refL = __float_as_uint(f0.w), refR = __float_as_uint(f1.w);
@@ -763,7 +764,7 @@ DEV void tri_test2(const DevScene& S, int k, float4 t0, float4 t1, float4 t2, fl
   if (COUNT) cn.tri_tests++;
   f3 A = mk3(t0), AB = mk3(t1), AC = mk3(t2), N = mk3(t3);
   float det = -dot3(orr.d, N);
-  if (ptm_abs(det) < kTmin) return;
+  if (ptm_abs(det) < S.tmin) return;
   f3 ao = orr.o - A;
   f3 dao = cross3(ao, orr.d);
   float invDet = rcp_exact_il(det);
@@ -771,7 +772,7 @@ DEV void tri_test2(const DevScene& S, int k, float4 t0, float4 t1, float4 t2, fl
   float u = dot3(AC, dao) * invDet;
   float v = -dot3(AB, dao) * invDet;
   float w = 1.0f - u - v;
-  if (dst < kTmin || dst > ct || u < kTmin || v < kTmin || w < kTmin) return;
+  if (dst < S.tmin || dst > ct || u < S.tmin || v < S.tmin || w < S.tmin) return;
   ct = dst;
   h.u = u, h.v = v;
   h.prim = (K_TRI << 28) | (uint32_t)k;

@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, 
       // triangles only when a batch of lanes waits for them, or nothing else can run
       const bool run_leaf = pm != 0ull && (__popcll(pm) >= leaf_batch || im == 0ull);
       uint32_t next = node;
-      if (isinner) next = inner_step2<COUNT, NOABORT>(f0, f1, f2, f3v, o, inv, negmask, ct, stack_size, stk, sp, cn);
+      if (isinner) next = inner_step2<COUNT, NOABORT>(f0, f1, f2, f3v, o, inv, S.tmin, negmask, ct, stack_size, stk, sp, cn);
       if (run_leaf && isleaf) {
         if (simple) {
           tri_test2<COUNT>(S, (int)(node & REF_IDX), f0, f1, f2, f3v, o, d, orr, ct, hit, cn);
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, 
       if (node < N_INNER_LIMIT) {
         const float4* rec = S.pairs + 4 * (size_t)node;
         const float4 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3v = rec[3];
-        node = inner_step2<COUNT, NOABORT>(f0, f1, f2, f3v, o, inv, negmask, ct, stack_size, stk, sp, cn);
+        node = inner_step2<COUNT, NOABORT>(f0, f1, f2, f3v, o, inv, S.tmin, negmask, ct, stack_size, stk, sp, cn);
         if (node == N_POP) node = pop_until_pass2(stk, sp, ct, cn, COUNT);
       }
       working = __popcll(__ballot(node != N_DONE));
@@ -522,14 +522,14 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
         f3 ldir = norm3(lp - g.p);
         f3 so = g.p, sd = ldir;
         float rnd = rand2D(rng);
-        if (rnd > 0.2f) {
+        if (rnd > rc.light_mix) {
           so = sorg;
           sd = sdir;
         }
         float cosine_theta = dot3(norm3(sd), unit_w);  // onb_lambertian_scattering_pdf :73-76
         float lambertian_pdf = ptm_max(0.0f, cosine_theta / kPi);
         float lpdf = light_pdf(L, so, sd);
-        float pdf = 0.2f * lpdf + 0.8f * lambertian_pdf;
+        float pdf = rc.light_mix * lpdf + rc.surface_mix * lambertian_pdf;  // 0.2 and 0.8 (traceRay.wgsl:43,49) by default
         if (pdf <= 0.00001f) {  // returns emission*throughput, dropping acc (Q8)
           drop_acc = true;
           sample_done = true;

@@ -224,6 +224,8 @@ static napi_value params_to_js(napi_env env, const ptmi_params* p) {
   set_i32(env, o, "stack_size", p->stack_size);
   set_f64(env, o, "fov_degrees", p->fov_degrees);
   set_i32(env, o, "frames_in_flight", p->frames_in_flight);
+  set_f64(env, o, "tmin", p->tmin);
+  set_f64(env, o, "light_mix", p->light_mix);
   CHECK_NAPI(napi_create_array_with_length(env, 3, &bg));
   for (uint32_t i = 0; i < 3; i++) {
     napi_value x;
@@ -273,9 +275,13 @@ static napi_value js_set_params(napi_env env, napi_callback_info info) {
   read_i32(env, a[1], "frames_in_flight", &p.frames_in_flight);
   bool has = false;
   napi_value v;
-  if (napi_has_named_property(env, a[1], "fov_degrees", &has) == napi_ok && has && napi_get_named_property(env, a[1], "fov_degrees", &v) == napi_ok) {
-    double d;
-    if (napi_get_value_double(env, v, &d) == napi_ok) p.fov_degrees = (float)d;
+  const char* fkeys[3] = {"fov_degrees", "tmin", "light_mix"};
+  float* fdst[3] = {&p.fov_degrees, &p.tmin, &p.light_mix};
+  for (int k = 0; k < 3; k++) {
+    if (napi_has_named_property(env, a[1], fkeys[k], &has) == napi_ok && has && napi_get_named_property(env, a[1], fkeys[k], &v) == napi_ok) {
+      double d;
+      if (napi_get_value_double(env, v, &d) == napi_ok) *fdst[k] = (float)d;
+    }
   }
   if (napi_has_named_property(env, a[1], "background", &has) == napi_ok && has && napi_get_named_property(env, a[1], "background", &v) == napi_ok) {
     for (uint32_t i = 0; i < 3; i++) {

@@ -15,7 +15,7 @@ BUF = {"spheres": 1, "quads": 2, "triangles": 5, "meshes": 6, "transforms": 7, "
 SYMBOLS = [
     "ptmi_version", "ptmi_status_string", "ptmi_last_error", "ptmi_create", "ptmi_create_multi", "ptmi_destroy", "ptmi_default_params",
     "ptmi_set_params", "ptmi_get_params", "ptmi_upload", "ptmi_resize", "ptmi_clear_framebuffer", "ptmi_set_shard",
-    "ptmi_render_frame", "ptmi_render", "ptmi_synchronize", "ptmi_prepare", "ptmi_read_framebuffer", "ptmi_write_framebuffer",
+    "ptmi_render_frame", "ptmi_render", "ptmi_synchronize", "ptmi_prepare", "ptmi_read_framebuffer", "ptmi_write_framebuffer", "ptmi_reduce_framebuffer",
     "ptmi_framebuffer_device_ptr", "ptmi_bind_framebuffer", "ptmi_stream", "ptmi_resolve_rgba8", "ptmi_set_counters",
     "ptmi_set_timing", "ptmi_get_stats", "ptmi_reset_stats", "ptmi_trace", "ptmi_math_eval", "ptmi_selftest", "ptmi_build_bvh",
     "ptmi_build_bvh_sah", "ptmi_build_bvh_device", "ptmi_obj_parse", "ptmi_free",
@@ -26,7 +26,7 @@ class Params(ctypes.Structure):
     _fields_ = [
         ("num_samples", ctypes.c_int32), ("max_bounces", ctypes.c_int32), ("stratify", ctypes.c_int32),
         ("importance_sampling", ctypes.c_int32), ("stack_size", ctypes.c_int32), ("background", ctypes.c_float * 3),
-        ("fov_degrees", ctypes.c_float), ("frames_in_flight", ctypes.c_int32), ("reserved", ctypes.c_int32 * 5),
+        ("fov_degrees", ctypes.c_float), ("frames_in_flight", ctypes.c_int32), ("tmin", ctypes.c_float), ("light_mix", ctypes.c_float), ("reserved", ctypes.c_int32 * 3),
     ]
 
 
@@ -92,6 +92,7 @@ def load_library(build=False):
     L.ptmi_synchronize.argtypes = [vp]
     L.ptmi_read_framebuffer.argtypes = [vp, fp, sz]
     L.ptmi_write_framebuffer.argtypes = [vp, fp, sz]
+    L.ptmi_reduce_framebuffer.argtypes = [vp]
     L.ptmi_framebuffer_device_ptr.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(sz)]
     L.ptmi_bind_framebuffer.argtypes = [vp, vp, sz]
     L.ptmi_stream.argtypes = [vp, ctypes.POINTER(vp)]
@@ -266,6 +267,10 @@ class Context:
         out = np.empty((self.height, self.width, 4), np.float32)
         self._ck(self.lib.ptmi_read_framebuffer(self.h, _ptr(out), out.nbytes))
         return out
+
+    def reduce_framebuffer(self):
+        """The one collective of a multi-device render (sum of the per-device buffers on the first device); a sync on one device."""
+        self._ck(self.lib.ptmi_reduce_framebuffer(self.h))
 
     def write_framebuffer(self, fb):
         a = np.ascontiguousarray(fb, np.float32)
