@@ -48,6 +48,12 @@ MS_KEY = {"k_bvh": "bvh_ms", "k_shade": "shade_ms", "k_generate": "generate_ms",
 LAUNCH_KEY = {"k_bvh": "intersect_launches", "k_shade": "shade_launches", "k_generate": "generate_launches", "k_accumulate": "accumulate_launches"}
 SPP = {"c2": 64, "c3": 256, "c4": 512, "c5": 1024}
 FETCH_MULT = {"k_bvh": 1.0}  # bytes per FETCH_SIZE byte, calibrated per access pattern (profiles/fetch_calib.json); streams: 2.0
+# The rate at which the chip's 256 L1 / texture-addresser paths serve per-lane gathers of 64-byte records (4 x global_load_dwordx4 per lane, every lane
+# its own record — k_bvh's fetch), measured by tools/gather_probe.hip (profiles/r03_gather_probe.json): 2.75-2.8 clocks per record per CU whether the table
+# sits in L1 (8 KB), in L2 (2 MB), is read lane-wise or quad-cooperatively, at 5 or 8 waves per SIMD; proportional to the lanes taking part
+# (profiles/r03_gather_probe2.json).  The same records from the Infinity Cache: 65 G/s, from HBM: 54 G/s.
+GATHER_PEAK_RECORDS_PER_S = 223.5e9
+GUIDE_MAX_CLOCK_GHZ = 2.4  # MI355X_MICROARCH.md "Max clock"
 
 
 def alg_bytes(st):
@@ -118,16 +124,19 @@ def make_context(pkg, wl, device, args):
 PMC_PASSES = (
     ("sq", "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_TRANS_F64"),
     ("fetch", "FETCH_SIZE SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32"),
-    ("write", "WRITE_SIZE"),
+    ("write", "WRITE_SIZE SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT"),
 )
 # Issue cost of a wave64 instruction on one SIMD, measured by tools/valu_peak.hip (profiles/valu_peak.json, throughput at 4-8 waves
 # per SIMD): 2 cycles for f32 add/mul/fma (and mov, and/or/xor, integer add), 4 for min/max, compares, shifts, conversions, integer
 # multiplies, packed f32, f64 arithmetic and the v_div_* helpers, 8 for f32 transcendentals, 16 for v_rcp_f64.  The counters
 # can tell the 2-, 8- and 16-cycle classes apart; everything else is charged 4 (moves and integer adds too: an over-estimate).
-def issue_cycles(p, L):
+def issue_cycles(p, L, int_at=4.0):
+    """Issue cycles per launch.  int_at: what an integer VALU instruction (SQ_INSTS_VALU_INT32: add / logic at 2 cycles, shifts and multiplies at 4)
+    is charged — 4 gives the upper bound the line's `valu_busy_frac` is, 3 the middle of the class (`valu_busy_frac_int_at_3`)."""
     fast = (p.get("SQ_INSTS_VALU_ADD_F32", 0.0) + p.get("SQ_INSTS_VALU_MUL_F32", 0.0) + p.get("SQ_INSTS_VALU_FMA_F32", 0.0)) / max(p.get("launches_fetch", L), 1)
     n, t32, t64 = p["SQ_INSTS_VALU"] / L, p.get("SQ_INSTS_VALU_TRANS_F32", 0.0) / L, p.get("SQ_INSTS_VALU_TRANS_F64", 0.0) / L
-    return 4.0 * n - 2.0 * min(fast, n) + 4.0 * t32 + 12.0 * t64
+    i32 = p.get("SQ_INSTS_VALU_INT32", 0.0) / max(p.get("launches_write", L), 1)
+    return 4.0 * n - 2.0 * min(fast, n) + 4.0 * t32 + 12.0 * t64 - (4.0 - int_at) * min(i32, n)
 
 
 def pmc_child(args):
@@ -202,13 +211,21 @@ def kernel_table(split, steps_in_split, pmc):
             busy = issue_cycles(p, L) / N_SIMD                        # issue cycles of this kernel's instruction mix, per SIMD and launch
             busy4 = 4.0 * p["SQ_ACTIVE_INST_VALU"] / N_SIMD / L       # SQ_ACTIVE_INST_VALU counts quad-cycles, at least one per instruction
             live_cyc = (ms / n * 1e-3) * clock if n and clock else cyc
+            lanes = p["SQ_THREAD_CYCLES_VALU"] / (64.0 * p["SQ_ACTIVE_INST_VALU"]) if p["SQ_ACTIVE_INST_VALU"] else None
+            busy_raw = busy / live_cyc if live_cyc else None
             e.update({
                 "valu_instr_per_launch": p["SQ_INSTS_VALU"] / L,
-                "valu_busy_frac": min(1.0, busy / live_cyc) if live_cyc else None,
+                "valu_busy_frac": min(1.0, busy_raw) if live_cyc else None,
+                "valu_busy_frac_unclamped_upper_bound": busy_raw,  # every instruction outside the f32 add/mul/fma, transcendental classes charged 4 cycles
+                "valu_busy_frac_int_at_3": (issue_cycles(p, L, 3.0) / N_SIMD / live_cyc) if live_cyc else None,
+                # the same busy cycles against the guide's 2.4 GHz instead of the clock the kernel actually ran at (DVFS loss shows up here)
+                "valu_busy_frac_at_2p4_ghz": (busy_raw * (clock / 1e9) / GUIDE_MAX_CLOCK_GHZ) if (live_cyc and clock) else None,
+                # issue slots that did useful work: busy fraction x active lanes per issued instruction
+                "lane_weighted_frac": (min(1.0, busy_raw) * lanes) if (live_cyc and lanes) else None,
                 "valu_busy_frac_4_cycles_per_instr": min(1.0, busy4 / live_cyc) if live_cyc else None,
                 "avg_cycles_per_valu_instr": issue_cycles(p, L) / (p["SQ_INSTS_VALU"] / L) if p["SQ_INSTS_VALU"] else None,
                 "wave_wait_frac": p["SQ_WAIT_ANY"] / p["SQ_WAVE_CYCLES"] if p["SQ_WAVE_CYCLES"] else None,
-                "active_lane_frac": p["SQ_THREAD_CYCLES_VALU"] / (64.0 * p["SQ_ACTIVE_INST_VALU"]) if p["SQ_ACTIVE_INST_VALU"] else None,
+                "active_lane_frac": lanes,
                 "clock_ghz_in_pmc_pass": clock / 1e9,
                 "pmc_pass_avg_launch_ms": p["pmc_ms_sq"] / L,
             })
@@ -226,32 +243,52 @@ def kernel_table(split, steps_in_split, pmc):
     return tab
 
 
-def roofline_of(tab, dom, timed_ms_per_launch, timed_launches):
-    """The contract's roofline object for the dominant kernel `dom`, in the unit of the bound it actually hits."""
+def roofline_of(tab, dom, timed_ms_per_launch, timed_launches, gather_records_per_launch=None):
+    """The contract's roofline object for the dominant kernel `dom`, in the unit of the bound it actually hits: the largest of
+    VALU issue (busy issue cycles of the kernel's own instruction mix), HBM (measured fabric bytes / 8 TB/s) and — for k_bvh — the L1 gather path
+    (64-byte records fetched per second / the rate tools/gather_probe.hip measures for that access pattern)."""
     e = tab[dom]
     vf, hf = e.get("valu_busy_frac"), e.get("hbm_frac")
     r = {"kernel": dom, "avg_launch_ms": timed_ms_per_launch, "launches": timed_launches, "share_of_kernel_time": e["share_of_kernel_time"],
          "traffic": e.get("hbm_bytes_per_launch")}
-    if vf is None and hf is None:
+    gf = None
+    if dom == "k_bvh" and gather_records_per_launch and timed_ms_per_launch:
+        gf = gather_records_per_launch / (timed_ms_per_launch * 1e-3) / GATHER_PEAK_RECORDS_PER_S
+    if vf is None and hf is None and gf is None:
         r.update({"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None})
         return r
     # re-base the fractions on the launch time measured inside the timed region
     scale = (e["avg_launch_ms"] / timed_ms_per_launch) if (timed_ms_per_launch and e["avg_launch_ms"]) else 1.0
     vf = min(1.0, vf * scale) if vf is not None else None
     hf = min(1.0, hf * scale) if hf is not None else None
-    if hf is not None and (vf is None or hf > vf):
+    best = max((x for x in (vf, hf, gf) if x is not None))
+    if gf is not None and gf == best:
+        gbs = gather_records_per_launch * 64.0 / (timed_ms_per_launch * 1e-3) / 1e9
+        r.update({"bound": "l1_gather", "achieved": gbs, "peak": GATHER_PEAK_RECORDS_PER_S * 64.0 / 1e9, "unit": "GB/s", "frac": gf,
+                  "peak_definition": "64-byte BVH / triangle records fetched per lane (pair fetches = reference node visits below the root / 2, plus triangle tests; exact counters) "
+                                     "x 64 B / launch time, against the rate the 256 CUs' L1 / texture-addresser paths deliver such per-lane gathers at: 223.5 G records/s = 2.75-2.8 clocks "
+                                     "per record per CU, the same from L1, from L2, lane-wise or quad-cooperative, at 5 or 8 waves per SIMD (tools/gather_probe.hip, "
+                                     "profiles/r03_gather_probe.json).  Evidence that this, not HBM / latency / VALU, bounds k_bvh: its rate per node visit does not move with the scene's "
+                                     "size from 1 MB to 134 MB of digests (profiles/r03_size_sweep.txt) nor with occupancy from 18 to 26 waves per CU (DESIGN.md §4)"})
+    elif hf is not None and hf == best:
         gbs = e["hbm_bytes_per_launch"] / (timed_ms_per_launch * 1e-3) / 1e9
         r.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
     else:
         rate = e["valu_instr_per_launch"] / (timed_ms_per_launch * 1e-3) / 1e9
         r.update({"bound": "valu_issue", "achieved": rate, "peak": rate / vf if vf else None, "unit": "G wave-instr/s", "frac": vf,
+                  "frac_is": "an UPPER bound of the VALU-busy fraction: instructions the counters cannot classify (moves, compares, min/max, conversions, integer) are charged 4 cycles although moves and "
+                             "integer adds issue in 2; see valu_busy_frac_int_at_3, frac_at_2p4_ghz and lane_weighted_frac next to it",
                   "peak_definition": "the rate at which this kernel's own instruction mix issues when no SIMD is ever idle: 1024 SIMDs x clock / "
                                      "(average issue cycles per wave64 instruction = %.2f: 2 for f32 add/mul/fma, 8 for f32 transcendentals, 16 for v_rcp_f64, 4 for "
                                      "everything else — classes measured by tools/valu_peak.hip, profiles/valu_peak.json; class counts from this run's SQ_INSTS_VALU_* counters)"
                                      % (e.get("avg_cycles_per_valu_instr") or 0.0)})
-    if max(vf or 0.0, hf or 0.0) < 0.5:
-        r["bound_note"] = "neither the VALU nor HBM is busy half the time: the kernel waits on memory latency (wave_wait_frac %.2f)" % (e.get("wave_wait_frac") or 0.0)
-    r["valu_busy_frac"], r["hbm_frac"] = vf, hf
+    if max(vf or 0.0, hf or 0.0, gf or 0.0) < 0.5:
+        r["bound_note"] = "no resource is busy half the time: the kernel waits on memory latency (wave_wait_frac %.2f)" % (e.get("wave_wait_frac") or 0.0)
+    r["valu_busy_frac"], r["hbm_frac"], r["l1_gather_frac"] = vf, hf, gf
+    # the honest distance to the ceiling (VERDICT round 2): the same busy cycles at the guide's 2.4 GHz, with integer instructions at 3 cycles, and weighted by active lanes
+    for k in ("valu_busy_frac_at_2p4_ghz", "valu_busy_frac_int_at_3", "lane_weighted_frac", "valu_busy_frac_unclamped_upper_bound", "clock_ghz_in_pmc_pass"):
+        if e.get(k) is not None:
+            r[{"valu_busy_frac_at_2p4_ghz": "frac_at_2p4_ghz"}.get(k, k)] = e[k] * (scale if k not in ("clock_ghz_in_pmc_pass",) else 1.0)
     return r
 
 
@@ -475,7 +512,12 @@ def main():
         st, cst, dom = m["st"], m["cst"], m["dom"]
         tab = kernel_table(m["split"], 1, pm)
         n_dom = max(st[LAUNCH_KEY[dom]], 1)
-        roof = roofline_of(tab, dom, st[MS_KEY[dom]] / n_dom, n_dom)
+        bvh_launches = max(m["split"][LAUNCH_KEY["k_bvh"]], 1)
+        gather = (cst["bvh_node_visits"] / 2.0 + cst["tri_tests"]) / bvh_launches  # 64-byte records k_bvh fetches per launch (pair records + triangle records)
+        roof = roofline_of(tab, dom, st[MS_KEY[dom]] / n_dom, n_dom, gather)
+        if tab["k_bvh"]["ms_per_step"] > 0:
+            tab["k_bvh"]["l1_gather_frac"] = gather * bvh_launches / (tab["k_bvh"]["ms_per_step"] * 1e-3) / GATHER_PEAK_RECORDS_PER_S
+            tab["k_bvh"]["records_per_launch"] = gather
         hit_scene_gbs = alg_bytes(cst) / (m["split"]["render_ms"] / 1e3) / 1e9 if m["split"]["render_ms"] > 0 else None
         roof["algorithmic_hit_scene_gbs_informational"] = hit_scene_gbs  # SURVEY §8d reference-layout bytes / render time: cache-oblivious, NOT a fraction of HBM peak
         roof["work_per_ray"] = {k: cst[k] / max(cst["rays"], 1) for k in ("node_visits", "bvh_node_visits", "tri_tests", "quad_tests", "sphere_tests", "mat_fetches")}

@@ -16,10 +16,16 @@ timeout -k 10 600 python bench.py --workload c3 --steps 2 --cpu-seconds 10 --ext
 timeout -k 10 600 python bench.py --workload c4 --steps 1 --cpu-seconds 10 --pmc-timeout 400 > $R/bench_c4.json 2> $R/bench_c4.err || exit 1
 timeout -k 10 600 python bench.py --workload c5 --width 3840 --height 2160 --spp 128 --steps 1 --cpu-seconds 10 --pmc-timeout 400 > $R/bench_c5.json 2> $R/bench_c5.err || exit 1
 # rocprofv3 kernel stats of the bench command itself (its own --pmc child passes off: one profiler at a time)
-for w in c2 c3; do
+for w in c2 c3 c4 c5; do
   rm -rf /tmp/ks_$w
-  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$w -o run -- python3 $root/bench.py --workload $w --steps 3 --warmup 1 --cpu-seconds 0 --pmc off --extra-configs off > $root/$R/ks_$w.log 2>&1) || exit 1
+  x=""; [ $w = c4 ] && x="--spp 128"; [ $w = c5 ] && x="--width 3840 --height 2160 --spp 64"
+  (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$w -o run -- python3 $root/bench.py --workload $w $x --steps 3 --warmup 1 --cpu-seconds 0 --pmc off --extra-configs off > $root/$R/ks_$w.log 2>&1) || exit 1
   cp $(find /tmp/ks_$w -name '*kernel_stats.csv' | head -1) $R/kernel_stats_$w.csv || exit 1
 done
 [ -x tools/valu_peak ] && timeout -k 10 300 tools/valu_peak > $R/valu_peak.json 2> $R/valu_peak.err
+# the gather path's ceiling (k_bvh's roofline) and the sweeps that show k_bvh sits on it
+[ -x tools/gather_probe ] && timeout -k 10 300 tools/gather_probe > $R/gather_probe.json 2> $R/gather_probe.err
+[ -x tools/gather_probe2 ] && timeout -k 10 300 tools/gather_probe2 > $R/gather_probe2.json 2> $R/gather_probe2.err
+bash tools/r3_size.sh > /dev/null 2>&1; cp gpurun_out/r3ab/size_sweep.txt $R/ 2>/dev/null
+bash tools/r3_coh.sh > /dev/null 2>&1; cp gpurun_out/r3ab/coherence.txt $R/ 2>/dev/null
 echo release pass done
