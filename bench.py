@@ -181,7 +181,7 @@ def pmc_passes(args, workload, log):
         for f in files:
             for row in csv.DictReader(open(f)):
                 k = row["Kernel_Name"].replace("ptmi::", "").replace("void ", "").split("(")[0].strip().split("<")[0]
-                k = {"k_bvh2": "k_bvh"}.get(k, k)  # the traversal kernel's second edition (round 3) is the same pipeline stage
+                k = {"k_bvh2": "k_bvh", "k_shade6": "k_shade"}.get(k, k)  # the traversal kernel's second edition and the 80-VGPR build of k_shade (round 3) are the same pipeline stages
                 if k not in KERNELS:
                     continue
                 rec = out.setdefault(k, {})

@@ -500,6 +500,10 @@ Paths paths_of(ptmi_ctx* c, int step, bool with_pixsum) {
 
 // the k_shade instance for a parameter combination (occupancy queries)
 const void* shade_kernel(bool is, bool so, bool cn, bool mu) {
+  if (!is && !mu) {  // progressive mode without importance sampling: the 80-VGPR build (k_shade6)
+    if (so) return cn ? reinterpret_cast<const void*>(&k_shade6<true, true>) : reinterpret_cast<const void*>(&k_shade6<true, false>);
+    return cn ? reinterpret_cast<const void*>(&k_shade6<false, true>) : reinterpret_cast<const void*>(&k_shade6<false, false>);
+  }
 #define PTMI_SK(I, S, C, M) \
   if (is == I && so == S && cn == C && mu == M) return reinterpret_cast<const void*>(&k_shade<I, S, C, M>)
   PTMI_SK(false, false, false, false); PTMI_SK(false, false, false, true); PTMI_SK(false, false, true, false); PTMI_SK(false, false, true, true);
@@ -670,7 +674,13 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
     }
     {
       ScopedSpan sp(c, T_SHADE);
-#define PTMI_LAUNCH_SHADE(IS, SO, CN, MU) hipLaunchKernelGGL((k_shade<IS, SO, CN, MU>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, c->d_heads.as<uint32_t>(), tot, s == 0 ? 1 : 0)
+#define PTMI_LAUNCH_SHADE(IS, SO, CN, MU)                                                                                                                        \
+  do {                                                                                                                                                          \
+    if (!(IS) && !(MU))                                                                                                                                         \
+      hipLaunchKernelGGL((k_shade6<SO, CN>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, c->d_heads.as<uint32_t>(), tot, s == 0 ? 1 : 0);      \
+    else                                                                                                                                                        \
+      hipLaunchKernelGGL((k_shade<IS, SO, CN, MU>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, c->d_heads.as<uint32_t>(), tot, s == 0 ? 1 : 0); \
+  } while (0)
 #define PTMI_LAUNCH_SHADE2(IS, SO)                          \
   do {                                                      \
     if (rc.num_samples > 1) {                               \

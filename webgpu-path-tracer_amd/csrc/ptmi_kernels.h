@@ -468,6 +468,17 @@ DEV void acc_store(const Paths& P, uint32_t pid, float4 v) {
   if (P.touched) P.touched[pid] = 1;
 }
 
+// The end of a path's only sample in progressive mode (NUM_SAMPLES == 1): acc_radiance += add; pixColor = (0 + acc_radiance) / 1.
+// `acc` is touched only when it changes: acc + (+-0) is acc bit for bit, and (0 + acc) / 1 is acc.
+DEV void end_sample_progressive(const Paths& P, uint32_t pid, f3 add) {
+  const bool changes = !(add.x == 0.0f && add.y == 0.0f && add.z == 0.0f);  // NaN counts as a change
+  if (changes) {
+    float4 A4 = acc_load(P, pid);
+    f3 fin = mk3(0, 0, 0) + (mk3(A4) + add);  // "/ NUM_SAMPLES" with NUM_SAMPLES == 1: x / 1.0f is x
+    acc_store(P, pid, make_float4(fin.x, fin.y, fin.z, __int_as_float(1)));
+  }  // else: (0 + acc) / 1 == acc, already in place — or never written, which k_accumulate reads as zero
+}
+
 // MULTI = NUM_SAMPLES > 1 (the per-pixel sample loop of shootRay.wgsl:5-49 lives in the slot: pixsum, in-slot camera ray); the
 // reference's progressive mode (NUM_SAMPLES = 1) compiles without it, which also frees the scalar registers the view matrix and
 // the image constants would occupy through the whole kernel.
@@ -575,13 +586,11 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
   // pathTrace (shootRay.wgsl:5-49): pixColor += ray_color(ray); pixColor /= NUM_SAMPLES
   if (!MULTI) {
     if (drop_acc) {
-      f3 fin = (mk3(0, 0, 0) + add) / rc.sample_div;
+      f3 fin = mk3(0, 0, 0) + add;  // (NUM_SAMPLES == 1: no division)
       acc_store(P, pid, make_float4(fin.x, fin.y, fin.z, __int_as_float(1)));
-    } else if (changes) {
-      float4 A4 = acc_load(P, pid);
-      f3 fin = (mk3(0, 0, 0) + (mk3(A4) + add)) / rc.sample_div;
-      acc_store(P, pid, make_float4(fin.x, fin.y, fin.z, __int_as_float(1)));
-    }  // else: (0 + acc) / 1 == acc, already in place — or never written, which k_accumulate reads as zero
+    } else {
+      end_sample_progressive(P, pid, add);
+    }
     return false;
   } else {
   float4 A4 = P.acc[pid];
@@ -605,6 +614,10 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
 #ifndef PTMI_SCHUNK
 #define PTMI_SCHUNK 512
 #endif
+#ifndef PTMI_MISS_SHORTCUT
+#define PTMI_MISS_SHORTCUT 1
+#endif
+constexpr bool kMissShortcut = PTMI_MISS_SHORTCUT != 0;  // A/B: settle definite misses in k_shade's flush phase
 constexpr int kSChunk = PTMI_SCHUNK;  // slots a k_shade block sorts, shades and compacts at a time
 
 // ray_color's loop body for one step, 512 slots at a time per block:
@@ -617,24 +630,23 @@ constexpr int kSChunk = PTMI_SCHUNK;  // slots a k_shade block sorts, shades and
 //      global atomic (16 or so per launch), fills it across chunks — an entry that does not fit any more continues in
 //      the next region — and marks what is left at the end as holes.
 template <bool IS, bool SORT, bool COUNT, bool MULTI>
-__global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads,
-                                                                  unsigned long long* __restrict__ totals, int first) {
+DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads, unsigned long long* __restrict__ totals,
+                    int first) {
   reset_heads(heads);
   __shared__ float4 s_q0[kSChunk], s_q1[kSChunk], s_q2[kSChunk];
   __shared__ uint16_t s_sorted[SORT ? kSChunk : 1];
   __shared__ uint32_t s_cnt[NUM_BINS + 2];
-  __shared__ uint32_t s_nout, s_next, s_cursor, s_rend, s_b0, s_n0, s_b1;
+  __shared__ uint32_t s_nout, s_next;
   const QuadL L = load_light(S);
   const int lane = lane_id();
   const uint32_t n = ctl->n_rays;
   // region size: a block handles about n / gridDim slots per launch; 1/16 of that per claim keeps both the
   // number of atomics and the holes left at the end (at most one region per block) small
   const uint32_t region = max((uint32_t)kSChunk, ((n / gridDim.x / 16u) + 511u) & ~511u);
-  if (threadIdx.x == 0) {
-    s_cursor = 0;
-    s_rend = 0;
-  }
+  const uint32_t wregion = region / (kBlock / 64);  // every wave fills output regions of its own (>= 128 slots): no barrier, no serial section in the flush phase
+  uint32_t w_cur = 0, w_rend = 0;                   // this wave's current output region [w_cur, w_rend) of the next queue (wave-uniform)
   uint32_t my_valid = 0;  // lane 0 of a wave: slots holding a path seen so far (= hitScene invocations)
+  uint32_t my_missed = 0;  // lane 0 of a wave: new rays that turned out to be misses in the flush phase (progressive mode)
   Counters cn = {0, 0, 0, 0, 0};
   // stage one survivor per lane in LDS, densely (one LDS atomic per wave)
   auto stage = [&](bool survive, const NewState& ns) {
@@ -736,63 +748,93 @@ __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, Re
       }
     }
     __syncthreads();
-    // ---- 3: place the survivors in the next queue ----
+    // ---- 3: hitScene part 1 for the survivors' new rays, then place them in the next queue ----
+    // A new ray that hits no sphere and no quad and misses the root box is a MISS already (hitScene returns false): in progressive
+    // mode its path ends here — background * throughput goes to acc_radiance now, exactly what the next step would have added as this
+    // path's last addition — instead of travelling through the queue to occupy a lane of a shading wave that has nothing to do for it
+    // (configs[1]: 4 of 10 rays leave the open box that way).  Its hitScene invocation is tallied for the next step, where it belongs.
     const uint32_t cnt = s_nout;
-    if (threadIdx.x == 0) {
-      uint32_t cur = s_cursor, rend = s_rend;
-      const uint32_t n0 = min(cnt, rend - cur);  // what still fits the current region
-      s_b0 = cur;
-      s_n0 = n0;
-      cur += n0;
-      if (cnt > n0) {  // claim the next region for the rest
-        const uint32_t want = max(region, cnt - n0);
-        uint32_t nb = atomicAdd(&ctl[1].n_rays, want);
-        if (nb + want > P.cap) {  // cannot happen with the host's sizing; never write out of bounds
+    uint32_t missed = 0;
+#pragma unroll 1
+    for (uint32_t q0 = (threadIdx.x & ~63u); q0 < cnt; q0 += kBlock) {  // one survivor per lane and pass; no barrier in here: every wave fills regions of its own
+      const uint32_t q = q0 + (uint32_t)lane;
+      bool keep = false;
+      float2 tp = make_float2(0.0f, 0.0f);
+      uint32_t hm = 0u, rng = 0u;
+      if (q < cnt) {
+        const float4 a0 = s_q0[q], a1 = s_q1[q];
+        rng = __float_as_uint(a0.w);
+        prims_for_ray<COUNT>(S, mk3(a0), mk3(a1), rng, tp, hm, cn);  // (hit_volume draws from the path's stream: rng goes back into the state)
+        if (kMissShortcut && !MULTI && hm == HITMAT_MISS) {  // traceRay.wgsl:12-16
+          end_sample_progressive(P, __float_as_uint(a1.w), mk3(rc.bg[0], rc.bg[1], rc.bg[2]) * mk3(s_q2[q]));
+          missed++;
+        } else {
+          keep = true;
+        }
+      }
+      const uint64_t km = __ballot(keep);
+      const uint32_t kept = (uint32_t)__popcll(km);
+      if (kept == 0) continue;
+      const uint32_t rank = lanes_below(km);
+      const uint32_t b0 = w_cur, n0 = min(kept, w_rend - w_cur);  // what still fits this wave's current region (wave-uniform)
+      uint32_t b1 = 0xffffffffu;
+      w_cur += n0;
+      if (kept > n0) {  // claim the wave's next region for the rest
+        uint32_t nb = 0;
+        if (lane == 0) nb = atomicAdd(&ctl[1].n_rays, wregion);
+        nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+        if (nb + wregion > P.cap) {  // cannot happen with the host's sizing; never write out of bounds
           // The survivors that still fit the current region are written as usual, the rest is dropped and the claim is
           // handed back (every later claim overflows too and does the same, so the queue length ends up within the buffer);
           // the host reports the flag as an error on the next synchronising call.
-          atomicAdd(&totals[15], 1ull);
-          atomicSub(&ctl[1].n_rays, want);
-          s_b1 = 0xffffffffu;
+          if (lane == 0) {
+            atomicAdd(&totals[15], 1ull);
+            atomicSub(&ctl[1].n_rays, wregion);
+          }
         } else {
-          s_b1 = nb;
-          cur = nb + (cnt - n0);
-          rend = nb + want;
+          b1 = nb;
+          w_cur = nb + (kept - n0);
+          w_rend = nb + wregion;
         }
       }
-      s_cursor = cur;
-      s_rend = rend;
-    }
-    __syncthreads();
-    {
-      const uint32_t b0 = s_b0, n0 = s_n0, b1 = s_b1;
-      for (uint32_t q = threadIdx.x; q < cnt; q += kBlock) {
-        if (q >= n0 && b1 == 0xffffffffu) break;
-        const uint32_t dst = (q < n0) ? (b0 + q) : (b1 + (q - n0));
+      if (keep && (rank < n0 || b1 != 0xffffffffu)) {
+        const uint32_t dst = (rank < n0) ? (b0 + rank) : (b1 + (rank - n0));
         float4 a0 = s_q0[q];
-        const float4 a1 = s_q1[q];
-        uint32_t rng = __float_as_uint(a0.w);
-        float2 tp;
-        uint32_t hm;
-        prims_for_ray<COUNT>(S, mk3(a0), mk3(a1), rng, tp, hm, cn);
-        a0.w = __uint_as_float(rng);  // hit_volume draws from the path's stream
+        a0.w = __uint_as_float(rng);
         P.out.q0[dst] = a0;
-        P.out.q1[dst] = a1;
+        P.out.q1[dst] = s_q1[q];
         P.out.q2[dst] = s_q2[q];
         P.hout.tp[dst] = tp;
         P.hout.mat[dst] = hm;
       }
     }
+    if (!MULTI) {
+      for (int off2 = 32; off2 > 0; off2 >>= 1) missed += __shfl_down(missed, off2, 64);
+      if (lane == 0) my_missed += missed;
+    }
     __syncthreads();
   }
+  if (lane == 0 && my_missed) atomicAdd(&ctl[1].n_valid, my_missed);  // hitScene invocations of the next step that were settled here
   if (lane == 0 && my_valid) atomicAdd(&ctl->n_valid, my_valid);
-  // what is left of the last region becomes holes
-  __syncthreads();
-  for (uint32_t i = s_cursor + threadIdx.x; i < s_rend; i += kBlock) {
+  // what is left of each wave's last region becomes holes
+  for (uint32_t i = w_cur + (uint32_t)lane; i < w_rend; i += 64u) {
     reinterpret_cast<uint32_t*>(P.out.q1 + i)[3] = PID_HOLE;
     P.hout.mat[i] = HITMAT_HOLE;
   }
   if (COUNT) reduce_counters(cn, totals, false);
+}
+
+// The kernel proper, twice: the progressive-mode variants without importance sampling fit 80 VGPRs — 6 waves per SIMD, which this
+// latency-bound kernel turns into throughput (round 3: 5 -> 6 blocks per CU, -8 %) —, the others need up to 96 (5 waves; at 80 they spill).
+template <bool IS, bool SORT, bool COUNT, bool MULTI>
+__global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads,
+                                                                  unsigned long long* __restrict__ totals, int first) {
+  shade_body<IS, SORT, COUNT, MULTI>(S, rc, P, ctl, heads, totals, first);
+}
+template <bool SORT, bool COUNT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_shade6(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl,
+                                                                                                uint32_t* __restrict__ heads, unsigned long long* __restrict__ totals, int first) {
+  shade_body<false, SORT, COUNT, false>(S, rc, P, ctl, heads, totals, first);
 }
 
 // main.wgsl:22-27 for the frame slots [f_begin, f_end) of the batch, in frame order; the call that folds slot 0 also
