@@ -60,6 +60,8 @@ def main():
         f.write("const NUM_SAMPLES = %d;\nconst MAX_BOUNCES = %d;\nconst STRATIFY = %s;\nconst IMPORTANCE_SAMPLING = %s;\nconst STACK_SIZE = %d;\n" % (
             p.num_samples, p.max_bounces, "true" if p.stratify else "false", "true" if p.importance_sampling else "false", p.stack_size))
         f.write("background_color (shaders/traceRay.wgsl:8) = vec3f(%g, %g, %g); fov = %g degrees (shaders/main.wgsl:7)\n" % (p.background[0], p.background[1], p.background[2], p.fov_degrees))
+        f.write("ray_tmin (shaders/header.wgsl:37) = %.9g; light / surface mixture (shaders/traceRay.wgsl:43,49) = %.9g / %.9g (only read when IMPORTANCE_SAMPLING)\n" % (
+            p.tmin, p.light_mix, float(np.float32(1.0) - np.float32(p.light_mix))))
         f.write("canvas %dx%d, camera eye (0.5,0,2.5) center (0.5,0,0) up (0,1,0) (index.js:40), frames 1..%d, resetBuffer 0\n" % (W, H, N))
     m = full[..., :3] / N
     print(json.dumps({"out": a.out, "frames": N, "mean_rgb": [float(x) for x in m.reshape(-1, 3).mean(0)], "half_mean_rgb": [float(x) for x in (h1[..., :3] / (N // 2)).reshape(-1, 3).mean(0)]}))

@@ -559,12 +559,16 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
   const int leaf_batch = env_int("PTMI_LEAF_BATCH", kLeafBatch);
   // PTMI_BVH_KERNEL: 1 = the first edition of the traversal kernel (rounds 1/2), 2 = second edition with one unified fetch per iteration,
   // 3 (default) = second edition's state machine in the first edition's two-phase loop — for A/B runs
-#define PTMI_LAUNCH_BVH_K(KERNEL)                                                                                                                                     \
+  const uint32_t range_cap = (uint32_t)std::max(64, std::min(1 << 16, env_int("PTMI_BVH_RANGE", (int)kBvhRange))) & ~63u;
+#define PTMI_LAUNCH_BVH_K1(KERNEL)                                                                                                                                    \
   hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), n_teams, c->prm.stack_size, le, se, c->d_spill.as<int2>(), thr, \
                      leaf_batch, tot)
+#define PTMI_LAUNCH_BVH_K(KERNEL)                                                                                                                                     \
+  hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), n_teams, c->prm.stack_size, le, se, c->d_spill.as<int2>(), thr, \
+                     leaf_batch, tot, range_cap)
 #define PTMI_LAUNCH_BVH(CNT, NA)                                       \
   do {                                                                 \
-    if (edition == 1) PTMI_LAUNCH_BVH_K((k_bvh<CNT, NA>));            \
+    if (edition == 1) PTMI_LAUNCH_BVH_K1((k_bvh<CNT, NA>));           \
     else if (edition == 2) PTMI_LAUNCH_BVH_K((k_bvh2<CNT, NA, true>)); \
     else PTMI_LAUNCH_BVH_K((k_bvh2<CNT, NA, false>));                  \
   } while (0)
@@ -577,6 +581,7 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
   }
 #undef PTMI_LAUNCH_BVH
 #undef PTMI_LAUNCH_BVH_K
+#undef PTMI_LAUNCH_BVH_K1
   HIP_TRY(c, hipGetLastError());
   return PTMI_OK;
 }

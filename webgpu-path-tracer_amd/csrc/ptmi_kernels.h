@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
 template <bool COUNT, bool NOABORT, bool UNIFIED>
 __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads, uint32_t n_teams, int stack_size,
                                                            int lds_entries, int spill_entries, int2* __restrict__ spill, int refill_threshold, int leaf_batch,
-                                                           unsigned long long* __restrict__ totals) {
+                                                           unsigned long long* __restrict__ totals, uint32_t range_cap) {
   extern __shared__ int lds_stack[];
   const int lane = lane_id();
   LaneStack2 stk;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, 
   stk.lds_entries = lds_entries;
   uint32_t* cand = reinterpret_cast<uint32_t*>(lds_stack + lds_entries * 2 * 64);  // [128] candidate slots
   const uint32_t n = ctl->n_rays;
-  const uint32_t range = min(kBvhRange, max(64u, ((n / (2u * gridDim.x)) + 63u) & ~63u));
+  const uint32_t range = min(range_cap, max(64u, ((n / (2u * gridDim.x)) + 63u) & ~63u));
   const uint32_t team = blockIdx.x % n_teams;
   Counters cn = {0, 0, 0, 0, 0};
   uint32_t rb = 0, re = 0;   // this wave's claimed range of slots still to be scanned (wave-uniform)
