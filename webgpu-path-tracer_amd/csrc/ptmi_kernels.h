@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kBlock) void k_prims(DevScene S, Paths P, const Ste
 constexpr int kRefillThreshold = 16;
 // The triangle phase of the flat traversal runs once this many lanes hold a pending leaf (or nothing else can run).
 constexpr int kLeafBatch = 16;
-constexpr uint32_t kBvhRange = 2048;  // slots a wave claims per global atomic (less when the queue is short)
+constexpr uint32_t kBvhRange = 512;  // slots a wave claims per global atomic (less when the queue is short); round 3: 256..1024 equal within noise, 2048 +1 %, 8192 +6 % (the last ranges are a tail)
 
 
 // hitScene, part 2 (hitRay.wgsl:42-110): BVH traversal by persistent, barrier-free waves.
