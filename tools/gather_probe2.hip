@@ -14,7 +14,7 @@ __device__ __forceinline__ uint32_t pcg(uint32_t& s) {
 }
 // WIDTH: float4 loads per record (4 = 64 B, 2 = 32 B, 1 = 16 B)
 template <int WIDTH>
-__global__ __launch_bounds__(256) void probe(const float4* __restrict__ table, uint32_t mask, uint32_t steps, int stride, int limit, float* __restrict__ sink) {
+__global__ __launch_bounds__(256) void probe(const float4* __restrict__ table, uint32_t mask, uint32_t steps, int stride, int limit, float* __restrict__ sink, int share = 1) {
   const int lane = threadIdx.x & 63;
   const bool on = (lane % stride == 0) && lane < limit;
   uint32_t s = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void probe(const float4* __restrict__ table, u
   float acc = 0.0f;
   if (on) {
     for (uint32_t k = 0; k < steps; k++) {
-      const float4* rec = table + 4 * (size_t)r;
+      const uint32_t rr = share > 1 ? (uint32_t)__shfl((int)r, lane & ~(share - 1), 64) : r;  // `share` neighbouring lanes fetch the same record
+      const float4* rec = table + 4 * (size_t)rr;
       float4 a = rec[0], b = a, c = a, d = a;
       if (WIDTH >= 2) b = rec[1];
       if (WIDTH >= 4) c = rec[2], d = rec[3];
@@ -93,6 +94,22 @@ int main() {
         first = false;
         fflush(stdout);
       }
+    }
+  }
+  // lanes sharing records: groups of 4 / 16 / 64 neighbouring lanes fetch the SAME 64-byte record (what coherent rays do at the top of a tree)
+  for (int share : {1, 4, 16, 64}) {
+    for (size_t bytes : {(size_t)64 << 10, (size_t)2 << 20}) {
+      for (int rep = 0; rep < 2; rep++) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(probe<4>, grid, block, 0, 0, table, (uint32_t)(bytes / 64 - 1), steps, 1, 64, sink, share);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+      }
+      float ms = 0;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      const double winstr = (double)cus * 5 * 4 * steps;
+      printf(",\n {\"what\": \"global, %d lanes per record\", \"bytes_per_lane\": 64, \"table_kb\": %zu, \"lanes\": \"64 lanes\", \"ms\": %.3f, \"clk_per_wave_fetch_per_cu\": %.1f, \"clk_per_record_per_cu\": %.2f}",
+             share, bytes >> 10, ms, ms * 1e-3 * (prop.clockRate * 1e3) / (winstr / cus), ms * 1e-3 * (prop.clockRate * 1e3) / (winstr / cus) / 64);
     }
   }
   printf("\n]}\n");
