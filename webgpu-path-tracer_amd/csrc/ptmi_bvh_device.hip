@@ -10,8 +10,11 @@
 //   * the pre-order id needs no counter: every leaf holds one primitive, a subtree over k primitives has 2k-1 nodes, so the
 //     children of node `id` over [start, end] split at mid are id+1 and id + 2*(mid-start+1); the skip link is handed down
 //     (left child: the right sibling; right child: the parent's link).
-// One level = one segmented reduce (6 doubles per primitive), one node kernel, one scan, one segmented sort, two element
-// kernels; ~21 levels for 871 k triangles.
+// One level = one device-wide reduce-by-key for the node boxes, one node kernel, one scan, TWO device-wide stable radix sorts
+// (by the f64 key, then by the start of the primitive's node: together a stable sort inside every node's range, whatever the
+// sizes of the ranges) and a few element kernels; ~21 levels for 871 k triangles.  (Round 2 used rocPRIM's SEGMENTED reduce and
+// sort: they give one workgroup to each large segment, so the first ~17 levels — 1, 2, 4 ... huge segments — took 4.5 ms each
+// and the GPU build lost to the host's threads: 118 ms against 98 for 871 k boxes.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -28,12 +31,16 @@ namespace {
 struct Box6 {
   double lo[3], hi[3];
 };
+// Math.min / Math.max (AABB.js:8-28): exact, and -0 < +0 whatever the argument order — so the reduction is associative and
+// commutative bit for bit and its order does not matter
+__host__ __device__ inline double js_min(double a, double b) { return (a < b || (a == b && (a != 0.0 || __builtin_signbit(a)))) ? a : b; }
+__host__ __device__ inline double js_max(double a, double b) { return (a > b || (a == b && (a != 0.0 || !__builtin_signbit(a)))) ? a : b; }
 struct BoxMerge {
   __host__ __device__ Box6 operator()(const Box6& a, const Box6& b) const {
     Box6 r;
     for (int k = 0; k < 3; k++) {
-      r.lo[k] = a.lo[k] < b.lo[k] ? a.lo[k] : b.lo[k];  // Math.min / Math.max on finite values
-      r.hi[k] = a.hi[k] > b.hi[k] ? a.hi[k] : b.hi[k];
+      r.lo[k] = js_min(a.lo[k], b.lo[k]);
+      r.hi[k] = js_max(a.hi[k], b.hi[k]);
     }
     return r;
   }
@@ -53,13 +60,6 @@ struct LevelNode {
   uint32_t id;          // pre-order id = row in the flattened array
   int32_t next;         // skip link (row id), -1 = none
 };
-// segment offsets of a level's nodes, read straight from the level array (end is inclusive: [start, end] = [start, end+1))
-struct NodeOffset {  // (rocPRIM wants one iterator type for both offsets)
-  const LevelNode* p;
-  uint32_t end;
-  __host__ __device__ uint32_t operator()(uint32_t j) const { return end ? p[j].end + 1u : p[j].start; }
-};
-
 // per node of the level: write its row, decide leaf / inner, choose the axis; inner[j] = 1 if it has children
 __global__ void k_level_rows(const LevelNode* __restrict__ nodes, const Box6* __restrict__ boxes, uint32_t m, int prim_type, float* __restrict__ rows,
                              int32_t* __restrict__ axis, uint32_t* __restrict__ inner) {
@@ -92,9 +92,9 @@ __global__ void k_level_rows(const LevelNode* __restrict__ nodes, const Box6* __
   inner[j] = leaf ? 0u : 1u;
 }
 
-// children of the inner nodes, in node order (left before right), and the sort segments of this level
+// children of the inner nodes, in node order (left before right)
 __global__ void k_level_children(const LevelNode* __restrict__ nodes, const uint32_t* __restrict__ inner, const uint32_t* __restrict__ rank, uint32_t m,
-                                 LevelNode* __restrict__ next_nodes, uint32_t* __restrict__ seg_begin, uint32_t* __restrict__ seg_end) {
+                                 LevelNode* __restrict__ next_nodes) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= m || !inner[j]) return;
   const LevelNode nd = nodes[j];
@@ -103,19 +103,43 @@ __global__ void k_level_children(const LevelNode* __restrict__ nodes, const uint
   const uint32_t lid = nd.id + 1u, rid = nd.id + 2u * (mid - nd.start + 1u);
   next_nodes[2 * r] = LevelNode{nd.start, mid, lid, (int32_t)rid};
   next_nodes[2 * r + 1] = LevelNode{mid + 1u, nd.end, rid, nd.next};
-  seg_begin[r] = nd.start;
-  seg_end[r] = nd.end + 1u;
 }
 
-// sort key of every primitive that sits in an inner node of this level; seg_of[i] = index of its node in the level, -1 = done
+// the boxes of the level's nodes out of the runs reduce_by_key found (a node's primitives are contiguous, so one run per node;
+// runs of finished primitives carry the key -1)
+__global__ void k_level_scatter_boxes(const int32_t* __restrict__ run_key, const Box6* __restrict__ run_box, const uint32_t* __restrict__ n_runs, uint32_t n,
+                                      Box6* __restrict__ boxes) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n || r >= *n_runs) return;
+  const int32_t j = run_key[r];
+  if (j >= 0) boxes[j] = run_box[r];
+}
+
+// Sort keys of this level.  A primitive in an inner node: minor key = bbox.min[axis] (with -0 -> +0: `a - b` treats them as equal),
+// major key = the start of its node's range; every other primitive (leaf reached, or finished earlier): major key = its own
+// position, so it stays where it is.  Ranges are disjoint and contiguous, hence "stable sort by minor, then stable sort by major" =
+// a stable sort by the minor key inside every range.  seg_of[i] = index of the primitive's node in the level, -1 = done.
 __global__ void k_level_keys(const uint32_t* __restrict__ order, const int32_t* __restrict__ seg_of, const int32_t* __restrict__ axis, const uint32_t* __restrict__ inner,
-                             const double* __restrict__ bmin, uint32_t n, double* __restrict__ keys) {
+                             const LevelNode* __restrict__ nodes, const double* __restrict__ bmin, uint32_t n, double* __restrict__ keys, uint64_t* __restrict__ packed) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int32_t j = seg_of[i];
+  const uint32_t p = order[i];
   double k = 0.0;
-  if (j >= 0 && inner[j]) k = bmin[3 * (size_t)order[i] + axis[j]] + 0.0;  // -0 -> +0: `a - b` treats them as equal
+  uint32_t major = i;
+  if (j >= 0 && inner[j]) {
+    k = bmin[3 * (size_t)p + axis[j]] + 0.0;
+    major = nodes[j].start;
+  }
   keys[i] = k;
+  packed[i] = ((uint64_t)major << 32) | p;
+}
+__global__ void k_level_unpack(const uint64_t* __restrict__ packed, uint32_t n, uint32_t* __restrict__ major, uint32_t* __restrict__ prim) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t v = packed[i];
+  major[i] = (uint32_t)(v >> 32);
+  prim[i] = (uint32_t)v;
 }
 
 // after the sort: which node of the NEXT level each primitive belongs to
@@ -162,48 +186,46 @@ struct Dev {  // frees everything on scope exit
     if (_e != hipSuccess) return _e;   \
   } while (0)
 
-hipError_t build_on_device(hipStream_t stream, uint32_t n, const double* h_bmin, const double* h_bmax, int prim_type, float* h_rows, int64_t* h_order) {
-  Dev d;
-  const uint32_t nn = 2 * n - 1;
-  double *bmin, *bmax, *keys[2];
-  uint32_t *order[2], *inner, *rank, *seg_begin, *seg_end;
-  int32_t *seg_of, *axis;
+// The level loop on boxes that are already on the device; leaves the rows (12 floats per node, 2n-1 nodes) and the primitive order on
+// the device too (the caller's buffers).  `d` owns the scratch.
+hipError_t build_levels(hipStream_t stream, Dev& d, uint32_t n, const double* bmin, const double* bmax, int prim_type, float* rows, uint32_t* order_out) {
+  double* keys[2];
+  uint64_t* packed[2];
+  uint32_t *order[2], *major[2], *inner, *rank, *n_runs;
+  int32_t *seg_of, *axis, *run_key;
   LevelNode* level[2];
-  Box6* boxes;
-  float* rows;
-  TRY(d.alloc(&bmin, 3 * (size_t)n));
-  TRY(d.alloc(&bmax, 3 * (size_t)n));
-  TRY(d.alloc(&keys[0], n));
-  TRY(d.alloc(&keys[1], n));
-  TRY(d.alloc(&order[0], n));
-  TRY(d.alloc(&order[1], n));
+  Box6 *boxes, *run_box;
+  for (int k = 0; k < 2; k++) {
+    TRY(d.alloc(&keys[k], n));
+    TRY(d.alloc(&packed[k], n));
+    TRY(d.alloc(&order[k], n));
+    TRY(d.alloc(&major[k], n));
+    TRY(d.alloc(&level[k], n));
+  }
   TRY(d.alloc(&seg_of, n));
   TRY(d.alloc(&inner, n));
   TRY(d.alloc(&rank, n));
-  TRY(d.alloc(&seg_begin, n));
-  TRY(d.alloc(&seg_end, n));
   TRY(d.alloc(&axis, n));
-  TRY(d.alloc(&level[0], n));
-  TRY(d.alloc(&level[1], n));
   TRY(d.alloc(&boxes, n));
-  TRY(d.alloc(&rows, 12 * (size_t)nn));
-  TRY(hipMemcpyAsync(bmin, h_bmin, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream));
-  TRY(hipMemcpyAsync(bmax, h_bmax, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream));
+  TRY(d.alloc(&run_key, n));
+  TRY(d.alloc(&run_box, n));
+  TRY(d.alloc(&n_runs, 1));
 
-  Box6 init;
-  for (int k = 0; k < 3; k++) init.lo[k] = 1e30, init.hi[k] = -1e30;  // new AABB() (AABB.js:2-5)
   const BoxOfPrim box_of{bmin, bmax};
+  unsigned major_bits = 1;
+  while ((1ull << major_bits) < (unsigned long long)n) major_bits++;
 
-  // temporary storage for the three rocPRIM calls at their largest size
-  size_t t_reduce = 0, t_scan = 0, t_sort = 0;
+  // temporary storage for the rocPRIM calls at their largest size
+  size_t t_reduce = 0, t_scan = 0, t_sort1 = 0, t_sort2 = 0;
   {
     auto in = rocprim::make_transform_iterator(order[0], box_of);
-    TRY(rocprim::segmented_reduce(nullptr, t_reduce, in, boxes, n, seg_begin, seg_end, BoxMerge(), init, stream));
+    TRY(rocprim::reduce_by_key(nullptr, t_reduce, seg_of, in, n, run_key, run_box, n_runs, BoxMerge(), rocprim::equal_to<int32_t>(), stream));
     TRY(rocprim::exclusive_scan(nullptr, t_scan, inner, rank, 0u, n, rocprim::plus<uint32_t>(), stream));
-    TRY(rocprim::segmented_radix_sort_pairs(nullptr, t_sort, keys[0], keys[1], order[0], order[1], n, n, seg_begin, seg_end, 0, 64, stream));
+    TRY(rocprim::radix_sort_pairs(nullptr, t_sort1, keys[0], keys[1], packed[0], packed[1], n, 0, 64, stream));
+    TRY(rocprim::radix_sort_pairs(nullptr, t_sort2, major[0], major[1], order[0], order[1], n, 0, major_bits, stream));
   }
   char* temp;
-  const size_t t_bytes = std::max(t_reduce, std::max(t_scan, t_sort));
+  const size_t t_bytes = std::max(std::max(t_reduce, t_scan), std::max(t_sort1, t_sort2));
   TRY(d.alloc(&temp, t_bytes));
 
   const unsigned B = 256;
@@ -215,15 +237,13 @@ hipError_t build_on_device(hipStream_t stream, uint32_t n, const double* h_bmin,
   uint32_t m = 1;
   int cur = 0, ocur = 0;  // ping-pong indices of the level arrays and of the order arrays
   while (m > 0) {
-    // node boxes: begin / end offsets of ALL nodes of the level (leaves included) come from the level array itself
+    // node boxes of ALL nodes of the level (leaves included): one run of equal seg_of per node
     {
-      auto idx = rocprim::counting_iterator<uint32_t>(0);
-      auto b = rocprim::make_transform_iterator(idx, NodeOffset{level[cur], 0u});
-      auto e = rocprim::make_transform_iterator(idx, NodeOffset{level[cur], 1u});
       auto in = rocprim::make_transform_iterator(order[ocur], box_of);
       size_t tb = t_bytes;
-      TRY(rocprim::segmented_reduce(temp, tb, in, boxes, m, b, e, BoxMerge(), init, stream));
+      TRY(rocprim::reduce_by_key(temp, tb, seg_of, in, n, run_key, run_box, n_runs, BoxMerge(), rocprim::equal_to<int32_t>(), stream));
     }
+    hipLaunchKernelGGL(k_level_scatter_boxes, dim3((n + B - 1) / B), dim3(B), 0, stream, run_key, run_box, n_runs, n, boxes);
     hipLaunchKernelGGL(k_level_rows, dim3((m + B - 1) / B), dim3(B), 0, stream, level[cur], boxes, m, prim_type, rows, axis, inner);
     {
       size_t tb = t_bytes;
@@ -236,13 +256,16 @@ hipError_t build_on_device(hipStream_t stream, uint32_t n, const double* h_bmin,
     TRY(hipStreamSynchronize(stream));
     const uint32_t n_inner = tail[0] + tail[1];
     if (n_inner == 0) break;
-    hipLaunchKernelGGL(k_level_children, dim3((m + B - 1) / B), dim3(B), 0, stream, level[cur], inner, rank, m, level[cur ^ 1], seg_begin, seg_end);
-    hipLaunchKernelGGL(k_level_keys, dim3((n + B - 1) / B), dim3(B), 0, stream, order[ocur], seg_of, axis, inner, bmin, n, keys[0]);
-    // primitives outside this level's inner nodes keep their place: start from a copy, the sort overwrites the segments
-    TRY(hipMemcpyAsync(order[ocur ^ 1], order[ocur], (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(k_level_children, dim3((m + B - 1) / B), dim3(B), 0, stream, level[cur], inner, rank, m, level[cur ^ 1]);
+    hipLaunchKernelGGL(k_level_keys, dim3((n + B - 1) / B), dim3(B), 0, stream, order[ocur], seg_of, axis, inner, level[cur], bmin, n, keys[0], packed[0]);
     {
       size_t tb = t_bytes;
-      TRY(rocprim::segmented_radix_sort_pairs(temp, tb, keys[0], keys[1], order[ocur], order[ocur ^ 1], n, n_inner, seg_begin, seg_end, 0, 64, stream));
+      TRY(rocprim::radix_sort_pairs(temp, tb, keys[0], keys[1], packed[0], packed[1], n, 0, 64, stream));  // stable, by bbox.min[axis]
+    }
+    hipLaunchKernelGGL(k_level_unpack, dim3((n + B - 1) / B), dim3(B), 0, stream, packed[1], n, major[0], order[ocur]);
+    {
+      size_t tb = t_bytes;
+      TRY(rocprim::radix_sort_pairs(temp, tb, major[0], major[1], order[ocur], order[ocur ^ 1], n, 0, major_bits, stream));  // stable, by node
     }
     ocur ^= 1;
     hipLaunchKernelGGL(k_level_descend, dim3((n + B - 1) / B), dim3(B), 0, stream, level[cur], inner, rank, n, seg_of);
@@ -250,9 +273,26 @@ hipError_t build_on_device(hipStream_t stream, uint32_t n, const double* h_bmin,
     m = 2 * n_inner;
   }
   TRY(hipGetLastError());
+  TRY(hipMemcpyAsync(order_out, order[ocur], (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+  return hipSuccess;
+}
+
+hipError_t build_on_device(hipStream_t stream, uint32_t n, const double* h_bmin, const double* h_bmax, int prim_type, float* h_rows, int64_t* h_order) {
+  Dev d;
+  const uint32_t nn = 2 * n - 1;
+  double *bmin, *bmax;
+  float* rows;
+  uint32_t* order;
+  TRY(d.alloc(&bmin, 3 * (size_t)n));
+  TRY(d.alloc(&bmax, 3 * (size_t)n));
+  TRY(d.alloc(&rows, 12 * (size_t)nn));
+  TRY(d.alloc(&order, n));
+  TRY(hipMemcpyAsync(bmin, h_bmin, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream));
+  TRY(hipMemcpyAsync(bmax, h_bmax, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream));
+  TRY(build_levels(stream, d, n, bmin, bmax, prim_type, rows, order));
   std::vector<uint32_t> ord(n);
   TRY(hipMemcpyAsync(h_rows, rows, 12 * (size_t)nn * sizeof(float), hipMemcpyDeviceToHost, stream));
-  TRY(hipMemcpyAsync(ord.data(), order[ocur], (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+  TRY(hipMemcpyAsync(ord.data(), order, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
   TRY(hipStreamSynchronize(stream));
   for (uint32_t i = 0; i < n; i++) h_order[i] = (int64_t)ord[i];
   return hipSuccess;

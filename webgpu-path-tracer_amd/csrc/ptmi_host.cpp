@@ -18,6 +18,10 @@
 #include "../../include/ptmi.h"
 
 namespace {
+// Math.min / Math.max (lib/BVH/AABB.js:8-28) on finite values: -0 < +0 whatever the argument order
+inline double js_min(double a, double b) { return (a < b || (a == b && (a != 0.0 || std::signbit(a)))) ? a : b; }
+inline double js_max(double a, double b) { return (a > b || (a == b && (a != 0.0 || !std::signbit(a)))) ? a : b; }
+
 
 // std::stable_sort with the upper levels of the merge tree forked: a stable sort's result is unique for a given order, so
 // halves sorted on their own threads + std::inplace_merge (stable) give exactly what one stable_sort call gives.
@@ -60,8 +64,8 @@ struct Builder {
       const double* a = bmin + 3 * order[i];
       const double* b = bmax + 3 * order[i];
       for (int k = 0; k < 3; k++) {
-        lo[k] = std::min(a[k], lo[k]);
-        hi[k] = std::max(b[k], hi[k]);
+        lo[k] = js_min(a[k], lo[k]);
+        hi[k] = js_max(b[k], hi[k]);
       }
     }
     double ext[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
@@ -168,8 +172,8 @@ struct Box {
   double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};  // new AABB()
   void merge(const double* a, const double* b) {                      // AABB.merge: min(a.min, this.min) ...
     for (int k = 0; k < 3; k++) {
-      lo[k] = std::min(a[k], lo[k]);
-      hi[k] = std::max(b[k], hi[k]);
+      lo[k] = js_min(a[k], lo[k]);
+      hi[k] = js_max(b[k], hi[k]);
     }
   }
   void merge(const Box& o) { merge(o.lo, o.hi); }

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kBlock) void k_prims(DevScene S, Paths P, const Ste
 }
 
 // A wave refills its idle lanes once this many lanes are idle (or all are).
-constexpr int kRefillThreshold = 16;
+constexpr int kRefillThreshold = 32;  // (round 3: 16 -> 32, configs[3] -3 %: idle lanes cost nothing on the gather path, and rays picked up together share their first fetches)
 // The triangle phase of the flat traversal runs once this many lanes hold a pending leaf (or nothing else can run).
 constexpr int kLeafBatch = 16;
 constexpr uint32_t kBvhRange = 512;  // slots a wave claims per global atomic (less when the queue is short); round 3: 256..1024 equal within noise, 2048 +1 %, 8192 +6 % (the last ranges are a tail)
