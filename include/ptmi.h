@@ -204,6 +204,17 @@ int ptmi_math_eval(ptmi_ctx* ctx, int fn, size_t n, const float* x, const float*
  * 2^32 arguments; 3 / 4: the bare v_rcp_f32 / v_sqrt_f32 instructions (controls that must report mismatches).  *mismatches = number of arguments whose bits differ (NaNs compare equal), *first_bad_bits = the smallest. */
 int ptmi_selftest(ptmi_ctx* ctx, int which, uint64_t* mismatches, uint32_t* first_bad_bits);
 
+/* Scene.create_bvh() (lib/scene.js:253-259 -> lib/BVH/bvhBuilder.js:6, bvhNode.js:28-73) for the triangles that are ALREADY uploaded (binding 5,
+ * in any order) with their meshes (6) and transforms (7): world-space boxes as lib/primitives/triangle.js:27-39 + AABB.js:35-51 compute
+ * them, the median-split build, and the reordering of the triangles into leaf order (lib/scene.js:257) — all on the GPU, nothing comes back:
+ * the BVH rows (byte-identical to ptmi_build_bvh's and the reference's) stay in device memory as binding 9 and the traversal digests are
+ * made from them there.  871 k triangles: ~15 ms (the reference's JavaScript: seconds; benchmarks.txt:19).  A later ptmi_upload(PTMI_BUF_BVH)
+ * replaces the tree; uploading other triangles requires building again. */
+int ptmi_build_scene_bvh(ptmi_ctx* ctx);
+/* Test / tool hook: copies the context's triangles (which = 5: in their current order) or BVH rows (which = 9) to the host; bytes must be
+ * exactly the buffer's size (triangles x 96, (2 x triangles - 1) x 48 for a tree from ptmi_build_scene_bvh). */
+int ptmi_read_scene_buffer(ptmi_ctx* ctx, int which, void* dst, size_t bytes);
+
 /* ---- host-side natives (no GPU needed) -------------------------------------------------------- */
 
 /* Median-split BVH build + pre-order flatten with the reference's exact semantics

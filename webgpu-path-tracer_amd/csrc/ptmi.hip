@@ -19,6 +19,11 @@
 
 using namespace ptmi;
 
+// csrc/ptmi_bvh_device.hip
+int ptmi_bvhdev_build_scene(void* stream, const float* d_tris, uint32_t n, const int32_t* h_meshes, int n_meshes, const float* h_xforms, int n_xforms, float* d_rows,
+                            float* d_tris_out, int* depth_out, uint32_t* bad_tri);
+int ptmi_bvhdev_make_pairs(void* stream, const float* d_rows, uint32_t nn, float* d_pairs);
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -72,6 +77,11 @@ struct ptmi_ctx {
   bool scene_dirty = true;
 
   DBuf d_quad_unit_n;
+  // ptmi_build_scene_bvh: the BVH rows (binding 9's layout) live on the device only — no host copy, pair64 made there too
+  DBuf d_bvh_rows;
+  bool bvh_on_device = false;
+  size_t bvh_dev_prims = 0;  // triangles the device-resident tree was built over
+  int bvh_dev_depth = 0;
   DBuf d_spheres, d_sphere_info, d_quads, d_quad_mat, d_tris, d_pretri, d_meshes, d_xforms, d_mats, d_pairs, d_leaf_table;
   DevScene S{};
   int bvh_depth = 0;             // max number of inner nodes on a root-to-leaf path
@@ -217,7 +227,7 @@ int prepare_scene(ptmi_ctx* c) {
   if (!c->scene_dirty) return PTMI_OK;
   const int n_sph = (int)(c->h_spheres.size() / 8), n_quad = (int)(c->h_quads.size() / 20), n_tri = (int)c->n_tris_uploaded;
   const int n_mesh = (int)(c->h_meshes.size() / 4), n_xf = (int)(c->h_xforms.size() / 32), n_mat = (int)(c->h_mats.size() / 16);
-  const int n_node = (int)(c->h_bvh.size() / 12);
+  const int n_node = c->bvh_on_device ? (int)(2 * c->bvh_dev_prims - 1) : (int)(c->h_bvh.size() / 12);
   char msg[256];
 
   c->has_unknown_material = false;
@@ -277,7 +287,29 @@ int prepare_scene(ptmi_ctx* c) {
   std::vector<int32_t> leaf_table;
   float root_lo[4] = {0, 0, 0, 0}, root_hi[4] = {0, 0, 0, 0};
   c->bvh_depth = 0;
-  if (n_node > 0) {
+  bool pairs_on_device = false;
+  if (n_node > 0 && c->bvh_on_device) {
+    // The tree came out of this library's own builder (ptmi_build_scene_bvh) over the triangles that are on the device: a tree by
+    // construction, every leaf one triangle of [0, n) — all that has to hold is that those triangles are still the uploaded ones.
+    if ((size_t)n_tri != c->bvh_dev_prims) {
+      snprintf(msg, sizeof msg, "the device-resident BVH was built over %zu triangles, %d are uploaded now (build again, or upload a BVH)", c->bvh_dev_prims, n_tri);
+      return fail(c, PTMI_ERR_BAD_SCENE, msg);
+    }
+    c->bvh_depth = c->bvh_dev_depth;
+    const size_t n_inner = (size_t)(n_node - 1) / 2;
+    HIP_TRY(c, c->d_pairs.ensure(std::max<size_t>(n_inner * 64, 16)));
+    if (n_inner) {
+      const int e = ptmi_bvhdev_make_pairs((void*)c->stream, c->d_bvh_rows.as<float>(), (uint32_t)n_node, c->d_pairs.as<float>());
+      if (e) return fail(c, e == (int)hipErrorOutOfMemory ? PTMI_ERR_NO_MEMORY : PTMI_ERR_DEVICE, std::string("pair records on the device: ") + hipGetErrorString((hipError_t)e));
+    }
+    float r0[12];
+    HIP_TRY(c, hipMemcpy(r0, c->d_bvh_rows.p, sizeof r0, hipMemcpyDeviceToHost));
+    const uint32_t rref = n_inner ? 0u : (REF_LEAF | (uint32_t)(int)r0[8]);  // the root is pair 0, or the only leaf
+    root_lo[0] = r0[0], root_lo[1] = r0[1], root_lo[2] = r0[2];
+    memcpy(&root_lo[3], &rref, 4);
+    root_hi[0] = r0[4], root_hi[1] = r0[5], root_hi[2] = r0[6];
+    pairs_on_device = true;
+  } else if (n_node > 0) {
     std::vector<uint8_t> seen((size_t)n_node, 0);  // 1 = inner, 2 = leaf
     std::vector<std::pair<int, int>> st;           // node, inner depth so far
     st.emplace_back(0, 0);
@@ -408,7 +440,7 @@ int prepare_scene(ptmi_ctx* c) {
   }
   HIP_TRY(c, up(c->d_xforms, c->h_xforms.data(), c->h_xforms.size() * 4));
   HIP_TRY(c, up(c->d_mats, c->h_mats.data(), c->h_mats.size() * 4));
-  HIP_TRY(c, up(c->d_pairs, pairs.data(), pairs.size() * 4));
+  if (!pairs_on_device) HIP_TRY(c, up(c->d_pairs, pairs.data(), pairs.size() * 4));
   HIP_TRY(c, up(c->d_leaf_table, leaf_table.data(), leaf_table.size() * 4));
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // the staging vectors die at scope exit
 
@@ -1047,7 +1079,7 @@ void ptmi_destroy(ptmi_ctx* c) {
   for (DBuf* b : {&c->d_quad_unit_n, &c->d_spheres, &c->d_sphere_info, &c->d_quads, &c->d_quad_mat, &c->d_tris, &c->d_pretri, &c->d_meshes, &c->d_xforms,
                   &c->d_mats, &c->d_pairs, &c->d_leaf_table, &c->d_fb_own, &c->d_q0[0], &c->d_q0[1], &c->d_q1[0], &c->d_q1[1], &c->d_q2[0],
                   &c->d_q2[1], &c->d_tp[0], &c->d_tp[1], &c->d_hm[0], &c->d_hm[1], &c->d_uv, &c->d_acc, &c->d_pixsum, &c->d_touched, &c->d_ctl, &c->d_totals,
-                  &c->d_scratch, &c->d_spill, &c->d_heads, &c->d_fb_gather, &c->d_fb_stage})
+                  &c->d_scratch, &c->d_spill, &c->d_heads, &c->d_fb_gather, &c->d_fb_stage, &c->d_bvh_rows})
     b->release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1117,7 +1149,10 @@ static int upload_commit(ptmi_ctx* c, int which, const void* data, size_t bytes,
     case PTMI_BUF_MESHES: c->h_meshes.assign((const int32_t*)data, (const int32_t*)data + bytes / 4); break;
     case PTMI_BUF_TRANSFORMS: c->h_xforms.assign(f, f + bytes / 4); break;
     case PTMI_BUF_MATERIALS: c->h_mats.assign(f, f + bytes / 4); break;
-    case PTMI_BUF_BVH: c->h_bvh.assign(f, f + bytes / 4); break;
+    case PTMI_BUF_BVH:
+      c->h_bvh.assign(f, f + bytes / 4);
+      c->bvh_on_device = false;  // an uploaded BVH replaces a device-resident one
+      break;
   }
   c->scene_dirty = true;
   c->ahead.valid = false;
@@ -1155,6 +1190,76 @@ int ptmi_upload(ptmi_ctx* c, int which, const void* data, size_t bytes) {
   for (size_t k = 0; k < n; k++) fresh[k].release();  // (only after a device error during the commit)
   (void)hipSetDevice(c->device);
   return rc;
+}
+
+// lib/scene.js:253-259 (create_bvh + the reordering of the triangles) on the GPU, over what is already there.
+static int build_scene_bvh_one(ptmi_ctx* c) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const size_t n = c->n_tris_uploaded;
+  if (n == 0) {
+    c->bvh_on_device = false;
+    c->h_bvh.clear();
+    c->scene_dirty = true;
+    return PTMI_OK;
+  }
+  if (n > ((size_t)1 << 27)) return fail(c, PTMI_ERR_UNSUPPORTED, "ptmi_build_scene_bvh: more than 2^27 triangles");
+  const int n_mesh = (int)(c->h_meshes.size() / 4), n_xf = (int)(c->h_xforms.size() / 32);
+  DBuf rows, tris2;
+  hipError_t e = rows.ensure((2 * n - 1) * 48);
+  if (e == hipSuccess) e = tris2.ensure(n * 96);
+  if (e != hipSuccess) {
+    rows.release();
+    tris2.release();
+    return fail(c, PTMI_ERR_NO_MEMORY, std::string("ptmi_build_scene_bvh: ") + hipGetErrorString(e));
+  }
+  int depth = 0;
+  uint32_t bad = 0xffffffffu;
+  const int r = ptmi_bvhdev_build_scene((void*)c->stream, c->d_tris.as<float>(), (uint32_t)n, c->h_meshes.data(), n_mesh, c->h_xforms.data(), n_xf, rows.as<float>(), tris2.as<float>(),
+                                         &depth, &bad);
+  if (r || bad != 0xffffffffu) {
+    rows.release();
+    tris2.release();
+    if (r) return fail(c, r == (int)hipErrorOutOfMemory ? PTMI_ERR_NO_MEMORY : PTMI_ERR_DEVICE, std::string("ptmi_build_scene_bvh: ") + hipGetErrorString((hipError_t)r));
+    char msg[160];
+    snprintf(msg, sizeof msg, "ptmi_build_scene_bvh: triangle %u: mesh_id / the mesh's global_id out of range (meshes %d, transforms %d)", bad, n_mesh, n_xf);
+    return fail(c, PTMI_ERR_BAD_SCENE, msg);
+  }
+  c->d_tris.release();  // the triangles now sit in leaf order (the reference reorders them on the host, lib/scene.js:257)
+  c->d_tris = tris2;
+  c->d_bvh_rows.release();
+  c->d_bvh_rows = rows;
+  c->bvh_on_device = true;
+  c->bvh_dev_prims = n;
+  c->bvh_dev_depth = depth;
+  c->h_bvh.clear();
+  c->scene_dirty = true;
+  c->ahead.valid = false;
+  return PTMI_OK;
+}
+
+int ptmi_build_scene_bvh(ptmi_ctx* c) {
+  if (!c) return PTMI_ERR_INVALID_ARG;
+  return on_all_devices(c, build_scene_bvh_one, true);
+}
+
+int ptmi_read_scene_buffer(ptmi_ctx* c, int which, void* dst, size_t bytes) {
+  if (!c || !dst) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_read_scene_buffer: null argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const void* src = nullptr;
+  size_t have = 0;
+  if (which == PTMI_BUF_TRIANGLES) src = c->d_tris.p, have = c->n_tris_uploaded * 96;
+  else if (which == PTMI_BUF_BVH && c->bvh_on_device) src = c->d_bvh_rows.p, have = (2 * c->bvh_dev_prims - 1) * 48;
+  else if (which == PTMI_BUF_BVH) {
+    have = c->h_bvh.size() * 4;
+    if (bytes != have) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_read_scene_buffer: byte size differs from the buffer's");
+    memcpy(dst, c->h_bvh.data(), have);
+    return PTMI_OK;
+  } else return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_read_scene_buffer: triangles (5) or bvh (9) only");
+  if (bytes != have) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_read_scene_buffer: byte size differs from the buffer's");
+  if (have) HIP_TRY(c, hipMemcpy(dst, src, have, hipMemcpyDeviceToHost));
+  return PTMI_OK;
 }
 
 int ptmi_resize(ptmi_ctx* c, int width, int height) {

@@ -188,7 +188,8 @@ struct Dev {  // frees everything on scope exit
 
 // The level loop on boxes that are already on the device; leaves the rows (12 floats per node, 2n-1 nodes) and the primitive order on
 // the device too (the caller's buffers).  `d` owns the scratch.
-hipError_t build_levels(hipStream_t stream, Dev& d, uint32_t n, const double* bmin, const double* bmax, int prim_type, float* rows, uint32_t* order_out) {
+hipError_t build_levels(hipStream_t stream, Dev& d, uint32_t n, const double* bmin, const double* bmax, int prim_type, float* rows, uint32_t* order_out,
+                        int* depth_out = nullptr) {
   double* keys[2];
   uint64_t* packed[2];
   uint32_t *order[2], *major[2], *inner, *rank, *n_runs;
@@ -236,7 +237,9 @@ hipError_t build_levels(hipStream_t stream, Dev& d, uint32_t n, const double* bm
 
   uint32_t m = 1;
   int cur = 0, ocur = 0;  // ping-pong indices of the level arrays and of the order arrays
+  int levels = 0;
   while (m > 0) {
+    levels++;
     // node boxes of ALL nodes of the level (leaves included): one run of equal seg_of per node
     {
       auto in = rocprim::make_transform_iterator(order[ocur], box_of);
@@ -274,6 +277,7 @@ hipError_t build_levels(hipStream_t stream, Dev& d, uint32_t n, const double* bm
   }
   TRY(hipGetLastError());
   TRY(hipMemcpyAsync(order_out, order[ocur], (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+  if (depth_out) *depth_out = levels - 1;  // inner nodes on the longest root-to-leaf path
   return hipSuccess;
 }
 
@@ -296,6 +300,73 @@ hipError_t build_on_device(hipStream_t stream, uint32_t n, const double* h_bmin,
   TRY(hipStreamSynchronize(stream));
   for (uint32_t i = 0; i < n; i++) h_order[i] = (int64_t)ord[i];
   return hipSuccess;
+}
+
+
+// ---- the scene's BVH built where the triangles already are (ptmi_build_scene_bvh) -------------------------------------------------
+// World-space box of every uploaded triangle exactly as the reference computes it on the host: vertices through the mesh's model
+// matrix in double (gl-matrix vec3.transformMat4 on f32 inputs, lib/primitives/triangle.js:27-39), stored as f32, min / max over
+// the three, then AABB.pad() (lib/BVH/AABB.js:35-51: an axis thinner than 0.00005 grows by that much on both sides).
+__global__ void k_scene_boxes(const float* __restrict__ tris, uint32_t n, const int32_t* __restrict__ meshes, int n_meshes, const float* __restrict__ xforms, int n_xforms,
+                              double* __restrict__ bmin, double* __restrict__ bmax, uint32_t* __restrict__ first_bad) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* t = tris + 24 * (size_t)i;
+  const float mf = t[23];  // mesh_id travels as a float (triangle.js:42-52)
+  int gid = -1;
+  if (mf >= 0.0f && mf < 2147483000.0f && (int)mf < n_meshes) gid = meshes[4 * (int)mf + 2];
+  if (gid < 0 || gid >= n_xforms) {
+    atomicMin(first_bad, i);
+    gid = -1;
+  }
+  double m[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  if (gid >= 0)
+    for (int k = 0; k < 16; k++) m[k] = (double)xforms[32 * (size_t)gid + k];
+  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  for (int v = 0; v < 3; v++) {
+    const double x = (double)t[4 * v], y = (double)t[4 * v + 1], z = (double)t[4 * v + 2];
+    double w = m[3] * x + m[7] * y + m[11] * z + m[15];
+    if (w == 0.0 || w != w) w = 1.0;  // `w = w || 1.0`
+    const double p[3] = {(double)(float)((m[0] * x + m[4] * y + m[8] * z + m[12]) / w), (double)(float)((m[1] * x + m[5] * y + m[9] * z + m[13]) / w),
+                         (double)(float)((m[2] * x + m[6] * y + m[10] * z + m[14]) / w)};
+    for (int k = 0; k < 3; k++) {
+      lo[k] = v == 0 ? p[k] : js_min(lo[k], p[k]);
+      hi[k] = v == 0 ? p[k] : js_max(hi[k], p[k]);
+    }
+  }
+  const double delta = 0.0001 / 2;
+  for (int k = 0; k < 3; k++) {
+    const bool thin = (hi[k] - lo[k]) < delta;
+    bmin[3 * (size_t)i + k] = thin ? lo[k] - delta : lo[k];
+    bmax[3 * (size_t)i + k] = thin ? hi[k] + delta : hi[k];
+  }
+}
+
+// triangles into BVH leaf order (lib/scene.js:257)
+__global__ void k_permute_triangles(const float4* __restrict__ src, const uint32_t* __restrict__ order, uint32_t n, float4* __restrict__ dst) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;  // one float4 (of the 6 per triangle) per thread
+  if (g >= 6u * n) return;
+  const uint32_t k = g / 6u, part = g - 6u * k;
+  dst[g] = src[6 * (size_t)order[k] + part];
+}
+
+// pair64 (csrc/ptmi_device.h) from rows that stay on the device: is_inner -> exclusive scan = the pair index, then one record per inner node
+__global__ void k_rows_inner_flag(const float* __restrict__ rows, uint32_t nn, uint32_t* __restrict__ inner) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nn) inner[i] = rows[12 * (size_t)i + 7] == -1.0f ? 1u : 0u;  // prim_type -1 = inner (bvhBuilder.js:45,49)
+}
+__global__ void k_rows_to_pairs(const float* __restrict__ rows, uint32_t nn, const uint32_t* __restrict__ inner, const uint32_t* __restrict__ rank, float* __restrict__ pairs) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nn || !inner[i]) return;
+  const float* nd = rows + 12 * (size_t)i;
+  const uint32_t L = i + 1u, R = (uint32_t)nd[3];
+  const float *nl = rows + 12 * (size_t)L, *nr = rows + 12 * (size_t)R;
+  auto ref_of = [&](uint32_t j, const float* row) -> uint32_t { return inner[j] ? rank[j] : (0x80000000u | (uint32_t)row[8]); };  // REF_LEAF | prim_id: one triangle per leaf
+  float* o = pairs + 16 * (size_t)rank[i];
+  o[0] = nl[0], o[1] = nl[1], o[2] = nl[2], o[3] = __uint_as_float(ref_of(L, nl));
+  o[4] = nl[4], o[5] = nl[5], o[6] = nl[6], o[7] = __uint_as_float(ref_of(R, nr));
+  o[8] = nr[0], o[9] = nr[1], o[10] = nr[2], o[11] = __int_as_float((int)nd[11]);
+  o[12] = nr[4], o[13] = nr[5], o[14] = nr[6], o[15] = 0.0f;
 }
 
 }  // namespace
@@ -321,4 +392,67 @@ extern "C" int ptmi_build_bvh_device(ptmi_ctx* ctx, size_t n_prims, const double
   }
   if (e != hipSuccess) return ptmi_ctx_fail(ctx, e == hipErrorOutOfMemory ? PTMI_ERR_NO_MEMORY : PTMI_ERR_DEVICE, hipGetErrorString(e));
   return PTMI_OK;
+}
+
+// ---- for ptmi.hip (ptmi_build_scene_bvh / prepare_scene): everything stays on the device -------------------------------------------
+// Builds the reference's median-split BVH over the n triangles at d_tris (24 f32 each, upload order): boxes, level loop, rows into
+// d_rows (12 f32 x (2n-1)), the triangles in leaf order into d_tris_out.  meshes / transforms are host arrays (small).  *bad_tri = first
+// triangle whose mesh / transform index is out of range (0xffffffff = none).  Returns a hipError_t.
+int ptmi_bvhdev_build_scene(void* stream_, const float* d_tris, uint32_t n, const int32_t* h_meshes, int n_meshes, const float* h_xforms, int n_xforms, float* d_rows,
+                            float* d_tris_out, int* depth_out, uint32_t* bad_tri) {
+  hipStream_t stream = (hipStream_t)stream_;
+  try {
+    Dev d;
+    double *bmin, *bmax;
+    int32_t* meshes;
+    float* xforms;
+    uint32_t *order, *bad;
+    TRY(d.alloc(&bmin, 3 * (size_t)n));
+    TRY(d.alloc(&bmax, 3 * (size_t)n));
+    TRY(d.alloc(&meshes, 4 * (size_t)n_meshes));
+    TRY(d.alloc(&xforms, 32 * (size_t)n_xforms));
+    TRY(d.alloc(&order, n));
+    TRY(d.alloc(&bad, 1));
+    const uint32_t none = 0xffffffffu;
+    TRY(hipMemcpyAsync(bad, &none, 4, hipMemcpyHostToDevice, stream));
+    if (n_meshes) TRY(hipMemcpyAsync(meshes, h_meshes, 16 * (size_t)n_meshes, hipMemcpyHostToDevice, stream));
+    if (n_xforms) TRY(hipMemcpyAsync(xforms, h_xforms, 128 * (size_t)n_xforms, hipMemcpyHostToDevice, stream));
+    const unsigned B = 256;
+    hipLaunchKernelGGL(k_scene_boxes, dim3((n + B - 1) / B), dim3(B), 0, stream, d_tris, n, meshes, n_meshes, xforms, n_xforms, bmin, bmax, bad);
+    TRY(hipMemcpyAsync(bad_tri, bad, 4, hipMemcpyDeviceToHost, stream));
+    TRY(hipStreamSynchronize(stream));
+    if (*bad_tri != none) return (int)hipSuccess;  // the caller reports it
+    TRY(build_levels(stream, d, n, bmin, bmax, 2, d_rows, order, depth_out));
+    hipLaunchKernelGGL(k_permute_triangles, dim3((6 * n + B - 1) / B), dim3(B), 0, stream, reinterpret_cast<const float4*>(d_tris), order, n,
+                       reinterpret_cast<float4*>(d_tris_out));
+    TRY(hipGetLastError());
+    TRY(hipStreamSynchronize(stream));  // the scratch dies with `d`
+    return (int)hipSuccess;
+  } catch (...) {
+    return (int)hipErrorOutOfMemory;
+  }
+}
+
+// pair64 records (16 f32 per inner node, (nn-1)/2 of them) from device-resident rows
+int ptmi_bvhdev_make_pairs(void* stream_, const float* d_rows, uint32_t nn, float* d_pairs) {
+  hipStream_t stream = (hipStream_t)stream_;
+  try {
+    Dev d;
+    uint32_t *inner, *rank;
+    char* temp;
+    TRY(d.alloc(&inner, nn));
+    TRY(d.alloc(&rank, nn));
+    size_t tb = 0;
+    TRY(rocprim::exclusive_scan(nullptr, tb, inner, rank, 0u, nn, rocprim::plus<uint32_t>(), stream));
+    TRY(d.alloc(&temp, tb));
+    const unsigned B = 256;
+    hipLaunchKernelGGL(k_rows_inner_flag, dim3((nn + B - 1) / B), dim3(B), 0, stream, d_rows, nn, inner);
+    TRY(rocprim::exclusive_scan(temp, tb, inner, rank, 0u, nn, rocprim::plus<uint32_t>(), stream));
+    hipLaunchKernelGGL(k_rows_to_pairs, dim3((nn + B - 1) / B), dim3(B), 0, stream, d_rows, nn, inner, rank, d_pairs);
+    TRY(hipGetLastError());
+    TRY(hipStreamSynchronize(stream));
+    return (int)hipSuccess;
+  } catch (...) {
+    return (int)hipErrorOutOfMemory;
+  }
 }

@@ -385,6 +385,16 @@ class Scene:
         out["triangles"] = self.get_triangles()
         return out
 
+    def buffers_unbuilt(self):
+        """The same arrays BEFORE create_bvh: the triangles in mesh order and no BVH — what ptmi_build_scene_bvh (the build on the GPU, over the
+        uploaded triangles) starts from.  Upload them (an empty `bvh`), then Context.build_scene_bvh()."""
+        self.init_mesh_data()
+        self.create_meshes()
+        return {
+            "meshes": self.get_meshes(), "spheres": self.get_spheres(), "quads": self.get_quads(), "materials": self.get_materials(),
+            "transforms": self.get_transforms(), "triangles": self.get_triangles(), "bvh": np.zeros(0, np.float32),
+        }
+
 
 # ----------------------------------------------------------------------------- lib/camera.js
 class Camera:

@@ -18,7 +18,7 @@ SYMBOLS = [
     "ptmi_render_frame", "ptmi_render", "ptmi_synchronize", "ptmi_prepare", "ptmi_read_framebuffer", "ptmi_write_framebuffer", "ptmi_reduce_framebuffer",
     "ptmi_framebuffer_device_ptr", "ptmi_bind_framebuffer", "ptmi_stream", "ptmi_resolve_rgba8", "ptmi_set_counters",
     "ptmi_set_timing", "ptmi_get_stats", "ptmi_reset_stats", "ptmi_trace", "ptmi_math_eval", "ptmi_selftest", "ptmi_build_bvh",
-    "ptmi_build_bvh_sah", "ptmi_build_bvh_device", "ptmi_obj_parse", "ptmi_free",
+    "ptmi_build_bvh_sah", "ptmi_build_bvh_device", "ptmi_build_scene_bvh", "ptmi_read_scene_buffer", "ptmi_obj_parse", "ptmi_free",
 ]
 
 
@@ -108,6 +108,8 @@ def load_library(build=False):
     L.ptmi_build_bvh.argtypes = [sz, fp, fp, i32, fp, fp]
     L.ptmi_build_bvh_sah.argtypes = [sz, fp, fp, i32, fp, fp, ctypes.POINTER(sz)]
     L.ptmi_build_bvh_device.argtypes = [vp, sz, fp, fp, i32, fp, fp]
+    L.ptmi_build_scene_bvh.argtypes = [vp]
+    L.ptmi_read_scene_buffer.argtypes = [vp, i32, fp, sz]
     L.ptmi_obj_parse.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(vp), ctypes.POINTER(sz)]
     L.ptmi_free.argtypes = [vp]
     L.ptmi_free.restype = None
@@ -318,6 +320,16 @@ class Context:
         order = np.zeros(n, np.int64)
         self._ck(self.lib.ptmi_build_bvh_device(self.h, n, _ptr(bmin), _ptr(bmax), prim_type, _ptr(nodes), _ptr(order)))
         return nodes, order
+
+    def build_scene_bvh(self):
+        """ptmi_build_scene_bvh: Scene.create_bvh() on the GPU over the uploaded (unordered) triangles, meshes and transforms; nothing comes back."""
+        self._ck(self.lib.ptmi_build_scene_bvh(self.h))
+
+    def read_scene_buffer(self, which, count):
+        """Test hook: the context's triangles ('triangles', count = number of triangles) or BVH rows ('bvh', count = number of nodes) as an array."""
+        out = np.empty((count, 24 if which == "triangles" else 12), np.float32)
+        self._ck(self.lib.ptmi_read_scene_buffer(self.h, BUF[which], _ptr(out), out.nbytes))
+        return out
 
     def trace(self, rays6, rng=None):
         r = np.ascontiguousarray(rays6, np.float32).reshape(-1, 6)
