@@ -53,6 +53,22 @@ __global__ __launch_bounds__(256) void probe_lds(const float4* __restrict__ tabl
   }
   if (acc == 12345.0f) sink[0] = acc;
 }
+// one dwordx4 per lane; groups of G lanes read consecutive pieces of a random (G*16)-byte-aligned block
+__global__ __launch_bounds__(256) void probe_contig(const float4* __restrict__ table, uint32_t mask16, uint32_t steps, int G, float* __restrict__ sink) {
+  const int lane = threadIdx.x & 63;
+  uint32_t s = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
+  uint32_t r = pcg(s);
+  float acc = 0.0f;
+  for (uint32_t k = 0; k < steps; k++) {
+    const uint32_t rr = (uint32_t)__shfl((int)r, lane & ~(G - 1), 64);     // the group's block
+    const uint32_t idx = ((rr * (uint32_t)G) + (uint32_t)(lane & (G - 1))) & mask16;
+    const float4 a = table[idx];
+    acc += a.x + a.w;
+    r = pcg(s) ^ __float_as_uint(a.x);
+  }
+  if (acc == 12345.0f) sink[0] = acc;
+}
+
 int main() {
   float4* table;
   float* sink;
@@ -110,6 +126,22 @@ int main() {
       const double winstr = (double)cus * 5 * 4 * steps;
       printf(",\n {\"what\": \"global, %d lanes per record\", \"bytes_per_lane\": 64, \"table_kb\": %zu, \"lanes\": \"64 lanes\", \"ms\": %.3f, \"clk_per_wave_fetch_per_cu\": %.1f, \"clk_per_record_per_cu\": %.2f}",
              share, bytes >> 10, ms, ms * 1e-3 * (prop.clockRate * 1e3) / (winstr / cus), ms * 1e-3 * (prop.clockRate * 1e3) / (winstr / cus) / 64);
+    }
+  }
+  // contiguity: groups of G neighbouring lanes read G consecutive 16-byte pieces (one dwordx4 per lane) of a random G*16-byte block
+  for (int G : {1, 4, 8, 16, 64}) {
+    for (size_t bytes : {(size_t)64 << 10, (size_t)2 << 20}) {
+      for (int rep = 0; rep < 2; rep++) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(probe_contig, grid, block, 0, 0, table, (uint32_t)(bytes / 16 - 1), steps, G, sink);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+      }
+      float ms = 0;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      const double winstr = (double)cus * 5 * 4 * steps;  // one load per step here
+      printf(",\n {\"what\": \"global, 1 x dwordx4 per lane, %d lanes contiguous\", \"bytes_per_lane\": 16, \"table_kb\": %zu, \"lanes\": \"64 lanes\", \"ms\": %.3f, \"clk_per_wave_fetch_per_cu\": %.1f, \"clk_per_record_per_cu\": %.2f}",
+             G, bytes >> 10, ms, ms * 1e-3 * (prop.clockRate * 1e3) / (winstr / cus), ms * 1e-3 * (prop.clockRate * 1e3) / (winstr / cus) / 64);
     }
   }
   printf("\n]}\n");
