@@ -95,3 +95,29 @@ def test_rccl_library_one_rank_communicator(pkg, oracle, monkeypatch):
     assert st["rays"] == ost["rays"]
     with pytest.raises(pkg.PtmiError):  # a communicator cannot hold one GPU twice
         pkg.Context([0, 0])
+
+
+def test_scene_bvh_built_on_every_device_and_the_collective_on_its_own(pkg, oracle):
+    """ptmi_build_scene_bvh on a multi-device context builds the tree on every device (deterministic: the same bytes everywhere), and
+    ptmi_reduce_framebuffer — the step's one collective as bench.py times it — leaves the image for ptmi_read_framebuffer: bit-identical to the
+    host pipeline on one device."""
+    sc = lambda: pkg.scenes.c3_scene(20011)
+    host = sc().buffers(native=pkg.ptmi.NativeHost())
+    view = cornell_view(pkg)
+    one, st1, _ = _render(pkg, 0, host, view, 128, 72, 3, max_bounces=5, stack_size=24)
+    with pkg.Context([0, 0, 0]) as ctx:
+        ctx.upload_scene(sc().buffers_unbuilt())
+        ctx.build_scene_bvh()
+        ctx.set_params(max_bounces=5, stack_size=24)
+        ctx.resize(128, 72)
+        ctx.set_counters(True)
+        ctx.render(view, 1, 3)
+        ctx.reduce_framebuffer()
+        got = ctx.read_framebuffer()
+        st = ctx.stats()
+        assert np.array_equal(ctx.read_scene_buffer("bvh", 2 * 20011 - 1).reshape(-1).view(np.uint32), np.asarray(host["bvh"], np.float32).view(np.uint32))
+    assert_same_bits(got, one, "three shards, trees built on the device")
+    for k in ("rays", "node_visits", "tri_tests", "quad_tests", "mat_fetches"):
+        assert st[k] == st1[k], k
+    want, ost = oracle.render(host, 128, 72, view, 1, 3, max_bounces=5, stack_size=24)
+    assert_same_bits(got, want, "vs oracle")
