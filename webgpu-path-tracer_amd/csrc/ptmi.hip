@@ -23,6 +23,7 @@ using namespace ptmi;
 int ptmi_bvhdev_build_scene(void* stream, const float* d_tris, uint32_t n, const int32_t* h_meshes, int n_meshes, const float* h_xforms, int n_xforms, float* d_rows,
                             float* d_tris_out, int* depth_out, uint32_t* bad_tri);
 int ptmi_bvhdev_make_pairs(void* stream, const float* d_rows, uint32_t nn, float* d_pairs);
+int ptmi_diag_sort_pairs(void* stream, uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, uint32_t n);
 
 namespace {
 
@@ -100,6 +101,7 @@ struct ptmi_ctx {
   size_t slot_cap = 0;  // slots per queue buffer (paths + room for the holes k_shade's regions leave)
   DBuf d_q0[2], d_q1[2], d_q2[2], d_tp[2], d_hm[2];  // slot-indexed live state and hit records, ping-pong
   DBuf d_uv, d_acc, d_pixsum, d_touched, d_ctl, d_totals, d_scratch, d_spill, d_heads;
+  DBuf d_diag[4];  // PTMI_DIAG_SORT: keys / slots, in / out
   int ctl_cap = 0;
 
   // Render-ahead of ptmi_render_frame (see there): per-frame colours of frames [frame0, frame0 + count) sit in d_acc,
@@ -564,6 +566,25 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
     else hipLaunchKernelGGL(k_prims<false>, dim3(pgrid), dim3(kBlock), 0, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), tot);
   }
   if (c->S.n_nodes <= 0) return PTMI_OK;
+  // PTMI_DIAG_SORT=1|2|3 (an experiment, never the product path): hand k_bvh the queue's rays fully sorted by direction octant and origin cell, to
+  // measure what ANY ordering of the queue could buy the traversal (the sort itself runs outside the kernel's timing span and is not counted).
+  const uint32_t* diag_order = nullptr;
+  const uint32_t* diag_keys = nullptr;
+  const int diag = env_int("PTMI_DIAG_SORT", 0);
+  if (diag > 0 && !with_prims) {
+    for (int k = 0; k < 4; k++) HIP_TRY(c, c->d_diag[k].ensure((size_t)max_items * 4));
+    hipLaunchKernelGGL(k_diag_sort_keys, dim3(pgrid), dim3(kBlock), 0, c->stream, P, ctl, diag, c->d_diag[0].as<uint32_t>(), c->d_diag[2].as<uint32_t>(), max_items);
+    uint32_t nq = 0;
+    HIP_TRY(c, hipMemcpyAsync(&nq, &ctl->n_rays, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    nq = std::min(nq, max_items);
+    if (nq > 0) {
+      const int e = ptmi_diag_sort_pairs((void*)c->stream, c->d_diag[0].as<uint32_t>(), c->d_diag[1].as<uint32_t>(), c->d_diag[2].as<uint32_t>(), c->d_diag[3].as<uint32_t>(), nq);
+      if (e) return fail(c, PTMI_ERR_DEVICE, std::string("PTMI_DIAG_SORT: ") + hipGetErrorString((hipError_t)e));
+      diag_keys = c->d_diag[1].as<uint32_t>();
+      diag_order = c->d_diag[3].as<uint32_t>();
+    }
+  }
   ScopedSpan sp(c, T_BVH);
   // Stack entries per lane: the first kLdsStackEntries in LDS, the rest (rarely reached) in a per-wave spill area.
   // 10 entries x 512 B + the candidate buffer = 5.5 KB per wave: 28 waves fit a CU's 160 KB, and the second-edition kernel's 66 VGPRs
@@ -597,7 +618,7 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
                      leaf_batch, tot)
 #define PTMI_LAUNCH_BVH_K(KERNEL)                                                                                                                                     \
   hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), n_teams, c->prm.stack_size, le, se, c->d_spill.as<int2>(), thr, \
-                     leaf_batch, tot, range_cap)
+                     leaf_batch, tot, range_cap, diag_order, diag_keys)
 #define PTMI_LAUNCH_BVH(CNT, NA)                                       \
   do {                                                                 \
     if (edition == 1) PTMI_LAUNCH_BVH_K1((k_bvh<CNT, NA>));           \
@@ -1079,7 +1100,7 @@ void ptmi_destroy(ptmi_ctx* c) {
   for (DBuf* b : {&c->d_quad_unit_n, &c->d_spheres, &c->d_sphere_info, &c->d_quads, &c->d_quad_mat, &c->d_tris, &c->d_pretri, &c->d_meshes, &c->d_xforms,
                   &c->d_mats, &c->d_pairs, &c->d_leaf_table, &c->d_fb_own, &c->d_q0[0], &c->d_q0[1], &c->d_q1[0], &c->d_q1[1], &c->d_q2[0],
                   &c->d_q2[1], &c->d_tp[0], &c->d_tp[1], &c->d_hm[0], &c->d_hm[1], &c->d_uv, &c->d_acc, &c->d_pixsum, &c->d_touched, &c->d_ctl, &c->d_totals,
-                  &c->d_scratch, &c->d_spill, &c->d_heads, &c->d_fb_gather, &c->d_fb_stage, &c->d_bvh_rows})
+                  &c->d_scratch, &c->d_spill, &c->d_heads, &c->d_fb_gather, &c->d_fb_stage, &c->d_bvh_rows, &c->d_diag[0], &c->d_diag[1], &c->d_diag[2], &c->d_diag[3]})
     b->release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;

@@ -275,7 +275,8 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
 template <bool COUNT, bool NOABORT, bool UNIFIED>
 __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads, uint32_t n_teams, int stack_size,
                                                            int lds_entries, int spill_entries, int2* __restrict__ spill, int refill_threshold, int leaf_batch,
-                                                           unsigned long long* __restrict__ totals, uint32_t range_cap) {
+                                                           unsigned long long* __restrict__ totals, uint32_t range_cap, const uint32_t* __restrict__ diag_order,
+                                                           const uint32_t* __restrict__ diag_keys) {
   extern __shared__ int lds_stack[];
   const int lane = lane_id();
   LaneStack2 stk;
@@ -330,8 +331,14 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, 
           rb = nb;
           re = min(nb + range, n);
         }
-        const uint32_t slot = rb + (uint32_t)lane;
-        const bool flagged = slot < re && (P.hin.mat[slot] & HITMAT_BVH) != 0u;
+        uint32_t slot = rb + (uint32_t)lane;
+        bool flagged;
+        if (diag_order) {  // PTMI_DIAG_SORT (an experiment): the queue's BVH rays in an explicit, fully sorted order instead of slot order
+          flagged = slot < re && diag_keys[slot] != 0xffffffffu;
+          if (flagged) slot = diag_order[slot];
+        } else {
+          flagged = slot < re && (P.hin.mat[slot] & HITMAT_BVH) != 0u;
+        }
         const uint64_t fm = __ballot(flagged);
         if (flagged) cand[ncand + lanes_below(fm)] = slot;
         ncand += (uint32_t)__popcll(fm);
@@ -427,6 +434,32 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, 
     }
   }
   if (COUNT) reduce_counters(cn, totals, true);
+}
+
+// PTMI_DIAG_SORT: sort key of every slot of a queue — 0xffffffff for slots k_bvh has nothing to do for; else direction octant and a 27-bit
+// Morton code of the origin in [-1.5, 1.5]^3 (mode 1: octant major, mode 2: origin major, mode 3: origin only).  Experiment only.
+DEV uint32_t diag_spread3(uint32_t v) {  // 9 bits -> every third bit
+  v &= 0x1ffu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+__global__ __launch_bounds__(kBlock) void k_diag_sort_keys(Paths P, const StepCtl* __restrict__ ctl, int mode, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t n_alloc) {
+  const uint32_t n = min(ctl->n_rays, n_alloc);
+  for (uint32_t slot = blockIdx.x * kBlock + threadIdx.x; slot < n; slot += gridDim.x * kBlock) {
+    uint32_t key = 0xffffffffu;
+    if (P.hin.mat[slot] & HITMAT_BVH) {
+      const float4 a0 = P.in.q0[slot], a1 = P.in.q1[slot];
+      const uint32_t oct = (a1.x < 0 ? 1u : 0u) | (a1.y < 0 ? 2u : 0u) | (a1.z < 0 ? 4u : 0u);
+      auto cell = [](float x) { return (uint32_t)fminf(fmaxf((x + 1.5f) * (512.0f / 3.0f), 0.0f), 511.0f); };
+      const uint32_t mort = diag_spread3(cell(a0.x)) | (diag_spread3(cell(a0.y)) << 1) | (diag_spread3(cell(a0.z)) << 2);  // 27 bits
+      key = mode == 1 ? ((oct << 27) | mort) : mode == 2 ? ((mort << 3) | oct) : mort;
+    }
+    keys[slot] = key;
+    vals[slot] = slot;
+  }
 }
 
 // What a surviving path carries into the next step's queue.
