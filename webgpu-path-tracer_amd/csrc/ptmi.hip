@@ -8,7 +8,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -63,6 +65,53 @@ struct DBuf {
 enum TimerTag { T_PRIMS = 0, T_SHADE = 1, T_GENERATE = 2, T_RENDER = 3, T_BVH = 4, T_ACCUM = 5 };
 
 }  // namespace
+
+// One persistent host thread per peer of a multi-device context: the calls that may block (allocation, the occasional queue-length
+// readback of a long render) run concurrently on all devices without starting a thread per call (ptmi_render_frame is per displayed frame).
+struct PeerWorker {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::function<int()> job;
+  int result = 0;
+  bool has_job = false, done = false, quit = false;
+  void loop() {
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      cv.wait(lk, [this] { return has_job || quit; });
+      if (quit) return;
+      std::function<int()> j = std::move(job);
+      has_job = false;
+      lk.unlock();
+      const int r = j();
+      lk.lock();
+      result = r;
+      done = true;
+      cv.notify_all();
+    }
+  }
+  void post(std::function<int()> j) {
+    std::lock_guard<std::mutex> lk(m);
+    if (!th.joinable()) th = std::thread([this] { loop(); });
+    job = std::move(j);
+    has_job = true;
+    done = false;
+    cv.notify_all();
+  }
+  int wait() {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [this] { return done; });
+    return result;
+  }
+  ~PeerWorker() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      quit = true;
+      cv.notify_all();
+    }
+    if (th.joinable()) th.join();
+  }
+};
 
 struct ptmi_ctx {
   int device = 0;
@@ -124,6 +173,7 @@ struct ptmi_ctx {
   // 1..n-1 (plain single-device contexts).  The caller's shard (ptmi_set_shard) is subdivided among the n of them.
   bool multi = false;
   std::vector<ptmi_ctx*> peers;
+  PeerWorker* worker = nullptr;  // a peer's host thread (created on first use)
   int proc_rank = 0, proc_world = 1, proc_tile = 4096;
   bool use_rccl = false;
   std::vector<ncclComm_t> comms;  // one per local device, same order as {this, peers...}
@@ -856,11 +906,13 @@ int on_all_devices(ptmi_ctx* c, F fn, bool parallel = false) {
   if (n == 0) return fn(c);
   std::vector<int> rcs(n + 1, PTMI_OK);
   if (parallel) {
-    std::vector<std::thread> th;
-    th.reserve(n);
-    for (size_t i = 0; i < n; i++) th.emplace_back([&rcs, &fn, c, i] { rcs[i + 1] = fn(c->peers[i]); });
+    for (size_t i = 0; i < n; i++) {
+      ptmi_ctx* q = c->peers[i];
+      if (!q->worker) q->worker = new PeerWorker();
+      q->worker->post([&fn, q] { return fn(q); });
+    }
     rcs[0] = fn(c);
-    for (auto& t : th) t.join();
+    for (size_t i = 0; i < n; i++) rcs[i + 1] = c->peers[i]->worker->wait();
   } else {
     rcs[0] = fn(c);
     for (size_t i = 0; i < n && !rcs[i]; i++) rcs[i + 1] = fn(c->peers[i]);  // stop at the first device that fails
@@ -1103,6 +1155,7 @@ void ptmi_destroy(ptmi_ctx* c) {
                   &c->d_scratch, &c->d_spill, &c->d_heads, &c->d_fb_gather, &c->d_fb_stage, &c->d_bvh_rows, &c->d_diag[0], &c->d_diag[1], &c->d_diag[2], &c->d_diag[3]})
     b->release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c->worker;
   delete c;
 }
 
