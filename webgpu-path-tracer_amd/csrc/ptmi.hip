@@ -560,8 +560,8 @@ int ensure_paths(ptmi_ctx* c, size_t npaths, int n_ctl, bool need_pixsum) {
   }
   HIP_TRY(c, c->d_heads.ensure(kMaxTeams * kHeadStride * sizeof(uint32_t)));
   if (!c->d_totals.p) {
-    HIP_TRY(c, c->d_totals.ensure(16 * sizeof(unsigned long long)));
-    HIP_TRY(c, hipMemsetAsync(c->d_totals.p, 0, 16 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, c->d_totals.ensure(kTotalsBytes));  // 16 persistent counters, then the tally lines of the batch in flight
+    HIP_TRY(c, hipMemsetAsync(c->d_totals.p, 0, kTotalsBytes, c->stream));
   }
   return PTMI_OK;
 }
@@ -758,6 +758,7 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   ScopedSpan whole(c, T_RENDER);
   c->batch_enqueued = true;  // from here on a failure leaves a partly traced batch behind: never retried
   HIP_TRY(c, hipMemsetAsync(ctl, 0, (size_t)(n_steps + 2) * sizeof(StepCtl), c->stream));
+  HIP_TRY(c, hipMemsetAsync(tot + 16, 0, kTotalsBytes - 128, c->stream));  // the batch's hitScene tally
   {
     ScopedSpan s(c, T_GENERATE);
     if (rc.num_samples == 1) HIP_TRY(c, hipMemsetAsync(c->d_touched.p, 0, npaths, c->stream));
@@ -785,7 +786,7 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
 #define PTMI_LAUNCH_SHADE(IS, SO, CN, MU)                                                                                                                        \
   do {                                                                                                                                                          \
     if (!(IS) && !(MU))                                                                                                                                         \
-      hipLaunchKernelGGL((k_shade6<SO, CN>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, c->d_heads.as<uint32_t>(), tot, s == 0 ? 1 : 0);      \
+      hipLaunchKernelGGL((k_shade6<SO, CN>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, c->d_heads.as<uint32_t>(), tot, s == 0 ? 1 : 0); \
     else                                                                                                                                                        \
       hipLaunchKernelGGL((k_shade<IS, SO, CN, MU>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, c->d_heads.as<uint32_t>(), tot, s == 0 ? 1 : 0); \
   } while (0)
@@ -815,7 +816,7 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   }
   {
     ScopedSpan s(c, T_ACCUM);
-    hipLaunchKernelGGL(k_accumulate, dim3(ew_grid), dim3(kBlock), 0, c->stream, rc, paths_of(c, 0, rc.num_samples > 1), c->fb, ctl, n_steps, tot, 0,
+    hipLaunchKernelGGL(k_accumulate, dim3(ew_grid), dim3(kBlock), 0, c->stream, rc, paths_of(c, 0, rc.num_samples > 1), c->fb, n_steps, tot, 0,
                        fold < 0 ? n_frames : std::min(fold, n_frames));
     c->stats.accumulate_launches++;
   }
@@ -1404,7 +1405,7 @@ static int render_frame_one(ptmi_ctx* c, const float* u) {
   c->last_frame = k;
   memcpy(c->last_view, view, 64);
   if (A.valid && follows && A.next < A.count && k == A.frame0 + (uint32_t)A.next && memcmp(view, A.view, 64) == 0) {
-    hipLaunchKernelGGL(k_accumulate, dim3(A.grid), dim3(kBlock), 0, c->stream, A.rc, paths_of(c, 0, A.rc.num_samples > 1), c->fb, c->d_ctl.as<StepCtl>(), 0,
+    hipLaunchKernelGGL(k_accumulate, dim3(A.grid), dim3(kBlock), 0, c->stream, A.rc, paths_of(c, 0, A.rc.num_samples > 1), c->fb, 0,
                        c->d_totals.as<unsigned long long>(), A.next, A.next + 1);
     HIP_TRY(c, hipGetLastError());
     A.next++;

@@ -229,10 +229,19 @@ struct Paths {
   uint32_t cap;      // slots per queue buffer
 };
 
-struct StepCtl {
-  uint32_t n_rays;   // slots of this step's queue (holes included)
-  uint32_t n_valid;  // slots that hold a path = hitScene invocations of this step (tallied by k_shade)
+// One 128-byte line per step: k_shade's blocks and waves claim their output regions of the NEXT step's queue with atomics on n_rays, and
+// same-line atomics serialise in one L2 channel at ~11 ns each — nothing else may share the line.
+struct alignas(128) StepCtl {
+  uint32_t n_rays;  // slots of this step's queue (holes included)
+  uint32_t pad[31];
 };
+// The hitScene tally of the batch being traced (slots that held a path, summed over its steps) is spread over kTallyLines counters on
+// lines of their own behind the 16 persistent totals (zeroed when a batch starts, added up by the k_accumulate call that folds its slot 0).
+constexpr int kTallyLines = 32;
+constexpr size_t kTotalsBytes = 128 + (size_t)kTallyLines * 128;
+DEV uint32_t* tally_line(unsigned long long* totals, uint32_t k) {
+  return reinterpret_cast<uint32_t*>(totals + 16) + (k % (uint32_t)kTallyLines) * 32u;
+}
 
 struct RenderConst {
   float W, H;

@@ -678,6 +678,12 @@ DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, St
   const uint32_t region = max((uint32_t)kSChunk, ((n / gridDim.x / 16u) + 511u) & ~511u);
   const uint32_t wregion = region / (kBlock / 64);  // every wave fills output regions of its own (>= 128 slots): no barrier, no serial section in the flush phase
   uint32_t w_cur = 0, w_rend = 0;                   // this wave's current output region [w_cur, w_rend) of the next queue (wave-uniform)
+  // The waves' FIRST regions come from one claim per block, made by whichever wave needs a region first; the others pick their quarter
+  // up from LDS (a launch made at least one claim per wave before: 6144 atomics on one address ~ 70 us — of a tail step with 100 us of
+  // work).  A block without survivors claims nothing, so a queue of holes still dies out.
+  constexpr uint32_t kR0Empty = 0xffffffffu, kR0Busy = 0xfffffffeu, kR0Full = 0xfffffffdu;
+  __shared__ uint32_t s_region0;
+  if (threadIdx.x == 0) s_region0 = kR0Empty;  // (visible after the first barrier of the chunk loop)
   uint32_t my_valid = 0;  // lane 0 of a wave: slots holding a path seen so far (= hitScene invocations)
   uint32_t my_missed = 0;  // lane 0 of a wave: new rays that turned out to be misses in the flush phase (progressive mode)
   Counters cn = {0, 0, 0, 0, 0};
@@ -814,16 +820,43 @@ DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, St
       w_cur += n0;
       if (kept > n0) {  // claim the wave's next region for the rest
         uint32_t nb = 0;
-        if (lane == 0) nb = atomicAdd(&ctl[1].n_rays, wregion);
-        nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
-        if (nb + wregion > P.cap) {  // cannot happen with the host's sizing; never write out of bounds
-          // The survivors that still fit the current region are written as usual, the rest is dropped and the claim is
-          // handed back (every later claim overflows too and does the same, so the queue length ends up within the buffer);
-          // the host reports the flag as an error on the next synchronising call.
-          if (lane == 0) {
+        bool full;
+        if (w_rend == 0u) {  // the wave's first region: its quarter of the block's claim
+          if (lane == 0) nb = atomicCAS(&s_region0, kR0Empty, kR0Busy);
+          nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+          if (nb == kR0Empty) {  // ours to make
+            if (lane == 0) {
+              nb = atomicAdd(&ctl[1].n_rays, region);
+              if (nb + region > P.cap) {  // cannot happen with the host's sizing, see below
+                atomicAdd(&totals[15], 1ull);
+                atomicSub(&ctl[1].n_rays, region);
+                nb = kR0Full;
+              }
+              atomicExch(&s_region0, nb);
+            }
+            nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+          } else {
+            while (nb == kR0Busy) {  // another wave of the block is at it: a global atomic's round trip
+              __builtin_amdgcn_s_sleep(8);
+              if (lane == 0) nb = atomicAdd(&s_region0, 0u);
+              nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+            }
+          }
+          full = nb == kR0Full;
+          nb += (threadIdx.x >> 6) * wregion;
+        } else {
+          if (lane == 0) nb = atomicAdd(&ctl[1].n_rays, wregion);
+          nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+          full = nb + wregion > P.cap;
+          if (full && lane == 0) {
             atomicAdd(&totals[15], 1ull);
             atomicSub(&ctl[1].n_rays, wregion);
           }
+        }
+        if (full) {  // cannot happen with the host's sizing; never write out of bounds
+          // The survivors that still fit the current region are written as usual, the rest is dropped and the claim is
+          // handed back (every later claim overflows too and does the same, so the queue length ends up within the buffer);
+          // the host reports the flag as an error on the next synchronising call.
         } else {
           b1 = nb;
           w_cur = nb + (kept - n0);
@@ -847,9 +880,13 @@ DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, St
     }
     __syncthreads();
   }
-  if (lane == 0 && my_missed) atomicAdd(&ctl[1].n_valid, my_missed);  // hitScene invocations of the next step that were settled here
-  if (lane == 0 && my_valid) atomicAdd(&ctl->n_valid, my_valid);
-  // what is left of each wave's last region becomes holes
+  // hitScene invocations: this step's slots that held a path + the next step's that were settled here; one of kTallyLines counters per block
+  if (lane == 0 && my_missed + my_valid) atomicAdd(tally_line(totals, blockIdx.x), my_missed + my_valid);
+  // what is left of each wave's last region becomes holes — all of its quarter of the block's claim if it never needed one
+  if (w_rend == 0u && blockIdx.x * (uint32_t)kSChunk < n && s_region0 < kR0Full) {  // (a block without a chunk passed no barrier: s_region0 is not its to read)
+    w_cur = s_region0 + (threadIdx.x >> 6) * wregion;
+    w_rend = w_cur + wregion;
+  }
   for (uint32_t i = w_cur + (uint32_t)lane; i < w_rend; i += 64u) {
     reinterpret_cast<uint32_t*>(P.out.q1 + i)[3] = PID_HOLE;
     P.hout.mat[i] = HITMAT_HOLE;
@@ -872,7 +909,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) 
 
 // main.wgsl:22-27 for the frame slots [f_begin, f_end) of the batch, in frame order; the call that folds slot 0 also
 // tallies the batch's rays/paths.  (ptmi_render_frame's render-ahead folds one slot per call.)
-__global__ __launch_bounds__(kBlock) void k_accumulate(RenderConst rc, Paths P, float4* __restrict__ fb, const StepCtl* __restrict__ ctl, int n_steps,
+__global__ __launch_bounds__(kBlock) void k_accumulate(RenderConst rc, Paths P, float4* __restrict__ fb, int n_steps,
                                                        unsigned long long* __restrict__ totals, int f_begin, int f_end) {
   for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < rc.n_local; j += gridDim.x * kBlock) {
     uint32_t pix = local_to_pixel(rc, j);
@@ -892,7 +929,8 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(RenderConst rc, Paths P, 
   }
   if (f_begin == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
     unsigned long long rays = 0;
-    for (int s = 0; s < n_steps; s++) rays += ctl[s].n_valid;
+    if (n_steps > 0)
+      for (int k = 0; k < kTallyLines; k++) rays += *tally_line(totals, (uint32_t)k);
     totals[0] += rays;
     totals[1] += (unsigned long long)rc.n_local * (unsigned long long)rc.n_frames * (unsigned long long)rc.num_samples;
   }
