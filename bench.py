@@ -42,10 +42,11 @@ import __graft_entry__ as entry  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_SIMD = 1024           # 256 CUs x 4 SIMDs
 REF_DRAGON_MPATHS = 33.5  # reference/benchmarks.txt:18-20: 62 fps x 900x600 px, 1 path per pixel and frame (derived in BASELINE.md §1)
-KERNELS = ("k_generate", "k_bvh", "k_shade", "k_accumulate")
-TIMING_MODE = {"k_bvh": 2, "k_shade": 3, "k_generate": 4, "k_accumulate": 5}
-MS_KEY = {"k_bvh": "bvh_ms", "k_shade": "shade_ms", "k_generate": "generate_ms", "k_accumulate": "accumulate_ms"}
-LAUNCH_KEY = {"k_bvh": "intersect_launches", "k_shade": "shade_launches", "k_generate": "generate_launches", "k_accumulate": "accumulate_launches"}
+KERNELS = ("k_generate", "k_tail", "k_bvh", "k_shade", "k_accumulate")
+TIMING_MODE = {"k_bvh": 2, "k_shade": 3, "k_generate": 4, "k_accumulate": 5, "k_tail": 6}
+MS_KEY = {"k_bvh": "bvh_ms", "k_shade": "shade_ms", "k_generate": "generate_ms", "k_accumulate": "accumulate_ms", "k_tail": "tail_ms"}
+LAUNCH_KEY = {"k_bvh": "intersect_launches", "k_shade": "shade_launches", "k_generate": "generate_launches", "k_accumulate": "accumulate_launches",
+              "k_tail": "tail_launches"}
 SPP = {"c2": 64, "c3": 256, "c4": 512, "c5": 1024}
 FETCH_MULT = {"k_bvh": 1.0}  # bytes per FETCH_SIZE byte, calibrated per access pattern (profiles/fetch_calib.json); streams: 2.0
 # The rate at which the chip's 256 L1 / texture-addresser paths serve per-lane gathers of 64-byte records (4 x global_load_dwordx4 per lane, every lane

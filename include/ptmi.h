@@ -98,6 +98,9 @@ typedef struct ptmi_stats {
   uint64_t accumulate_launches;
   uint64_t devices;      /* GPUs behind this context (ptmi_create_multi); counters are summed over them, times are
                           * the maximum over them                                            */
+  double tail_ms;        /* sum over k_tail launches: short queues traced to the end in one launch (most decline
+                          * at once); counts towards neither intersect_ms nor shade_ms       */
+  uint64_t tail_launches;
 } ptmi_stats;
 
 /* One hitScene result, the fields of the reference's HitRecord (shaders/header.wgsl:119-125). */
@@ -185,8 +188,8 @@ int ptmi_stream(ptmi_ctx* ctx, void** stream);
 int ptmi_resolve_rgba8(ptmi_ctx* ctx, float frame_num, uint8_t* dst, size_t bytes);
 
 int ptmi_set_counters(ptmi_ctx* ctx, int enabled);
-/* 0 = off; 1 = HIP events around every kernel launch; 2 / 3 / 4 / 5 = only around k_bvh / k_shade / k_generate /
- * k_accumulate: fewer stream markers, for timing ONE kernel inside a region whose wall clock also matters. */
+/* 0 = off; 1 = HIP events around every kernel launch; 2 / 3 / 4 / 5 / 6 = only around k_bvh / k_shade / k_generate /
+ * k_accumulate / k_tail: fewer stream markers, for timing ONE kernel inside a region whose wall clock also matters. */
 int ptmi_set_timing(ptmi_ctx* ctx, int enabled);
 int ptmi_get_stats(ptmi_ctx* ctx, ptmi_stats* out); /* synchronises */
 int ptmi_reset_stats(ptmi_ctx* ctx);

@@ -50,7 +50,7 @@ def test_bench_line_contract_with_its_own_pmc_passes():
         assert k in d, k
     assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f32" and d["value"] > 0
     roof = d["roofline"]
-    assert roof["kernel"] in ("k_generate", "k_bvh", "k_shade", "k_accumulate") and roof["avg_launch_ms"] > 0
+    assert roof["kernel"] in ("k_generate", "k_tail", "k_bvh", "k_shade", "k_accumulate") and roof["avg_launch_ms"] > 0
     tab = roof["kernels"]
     assert abs(sum(v["share_of_kernel_time"] for v in tab.values()) - 1.0) < 1e-6
     assert roof["kernel"] == max(tab, key=lambda k: tab[k]["ms_per_step"])

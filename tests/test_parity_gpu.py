@@ -11,6 +11,20 @@ from conftest import assert_same_bits, cornell_view
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["wavefront", "mixed", "tail"])
+def pipeline(request, monkeypatch):
+    """Every case three times: through the wavefront kernels alone (k_generate, k_bvh, k_shade per bounce), with the library's default
+    hand-over (k_tail traces a step's queue to the end once it is at most 4 Mi slots long: the small cases never leave k_tail, the
+    full-size ones switch in mid-batch), and with k_tail taking every queue whole from step 0.  PTMI_TAIL_LIMIT is read per render."""
+    if request.param == "wavefront":
+        monkeypatch.setenv("PTMI_TAIL_LIMIT", "0")
+    elif request.param == "tail":
+        monkeypatch.setenv("PTMI_TAIL_LIMIT", str(1 << 30))
+    else:
+        monkeypatch.delenv("PTMI_TAIL_LIMIT", raising=False)
+    return request.param
+
+
 def _setup(ctx, pkg, name, w, h, **params):
     b = pkg.scenes.golden_buffers(name)
     ctx.upload_scene(b)

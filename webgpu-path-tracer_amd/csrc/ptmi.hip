@@ -62,7 +62,7 @@ struct DBuf {
   }
 };
 
-enum TimerTag { T_PRIMS = 0, T_SHADE = 1, T_GENERATE = 2, T_RENDER = 3, T_BVH = 4, T_ACCUM = 5 };
+enum TimerTag { T_PRIMS = 0, T_SHADE = 1, T_GENERATE = 2, T_RENDER = 3, T_BVH = 4, T_ACCUM = 5, T_TAIL = 6 };
 
 }  // namespace
 
@@ -221,7 +221,7 @@ struct ScopedSpan {  // records a begin/end event pair around launches when timi
   ptmi_ctx::Span s{};
   bool on;
   static bool wanted(int timing, int tag) {  // ptmi_set_timing: 1 = everything, 2..5 = one kernel only
-    return timing == 1 || (timing == 2 && tag == T_BVH) || (timing == 3 && tag == T_SHADE) || (timing == 4 && tag == T_GENERATE) || (timing == 5 && tag == T_ACCUM);
+    return timing == 1 || (timing == 2 && tag == T_BVH) || (timing == 3 && tag == T_SHADE) || (timing == 4 && tag == T_GENERATE) || (timing == 5 && tag == T_ACCUM) || (timing == 6 && tag == T_TAIL);
   }
   ScopedSpan(ptmi_ctx* c_, int tag) : c(c_), on(wanted(c_->timing, tag)) {
     if (!on) return;
@@ -245,6 +245,7 @@ void drain_spans(ptmi_ctx* c) {  // call after the stream is idle
       else if (s.tag == T_SHADE) c->stats.shade_ms += ms;
       else if (s.tag == T_GENERATE) c->stats.generate_ms += ms, c->stats.other_ms += ms;
       else if (s.tag == T_ACCUM) c->stats.accumulate_ms += ms, c->stats.other_ms += ms;
+      else if (s.tag == T_TAIL) c->stats.tail_ms += ms;
       else c->stats.render_ms += ms;
     }
     c->ev_pool.push_back(s.a);
@@ -326,12 +327,14 @@ int prepare_scene(ptmi_ctx* c) {
       snprintf(msg, sizeof msg, "mesh %d: global_id %d / material_id %d out of range (transforms %d, materials %d)", i, me[2], me[3], n_xf, n_mat);
       return fail(c, PTMI_ERR_BAD_SCENE, msg);
     }
-    use_class(me[3]);
   }
-  c->material_classes = __builtin_popcount(classes);
   // (the pretri digest is computed on the device from the uploaded triangles: k_pretri_digest, below)
   std::vector<int32_t> mesh_matword((size_t)n_mesh);
-  for (int i = 0; i < n_mesh; i++) mesh_matword[i] = mat_word[c->h_meshes[4 * (size_t)i + 3]];
+  for (int i = 0; i < n_mesh; i++) {
+    mesh_matword[i] = mat_word[c->h_meshes[4 * (size_t)i + 3]];
+    use_class(c->h_meshes[4 * (size_t)i + 3]);
+  }
+  c->material_classes = __builtin_popcount(classes);
   // Tree check + pair64 digest.  Children always have larger indices than their parent (left = i+1,
   // right > i+1), so a walk from the root terminates; "every node reached at most once" excludes
   // shared subtrees (which could make a traversal exponentially long).
@@ -657,7 +660,7 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
   // same-address global atomics serialise at ~11 ns each (configs[1]: +2 %).
   const uint32_t n_teams = std::max<uint32_t>(1, std::min<uint32_t>(kMaxTeams, (uint32_t)env_int("PTMI_BVH_TEAMS", 16)));
   // (the counters are zeroed by the kernel that filled this queue)
-  HIP_TRY(c, c->d_spill.ensure(std::max<size_t>(16, (size_t)grid * (size_t)se * 64 * sizeof(int2))));
+  HIP_TRY(c, c->d_spill.ensure(std::max<size_t>(16, (size_t)std::max<uint32_t>(grid, (uint32_t)c->num_cus * 32) * (size_t)se * 64 * sizeof(int2))));
   const int thr = env_int("PTMI_REFILL", kRefillThreshold);
   const int leaf_batch = env_int("PTMI_LEAF_BATCH", kLeafBatch);
   // PTMI_BVH_KERNEL: 1 = the first edition of the traversal kernel (rounds 1/2), 2 = second edition with one unified fetch per iteration,
@@ -686,6 +689,45 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
 #undef PTMI_LAUNCH_BVH_K
 #undef PTMI_LAUNCH_BVH_K1
   HIP_TRY(c, hipGetLastError());
+  return PTMI_OK;
+}
+
+// k_tail in front of a step: traces the step's queue to the end if it is short (PTMI_TAIL_LIMIT slots, 0 = never launched), else returns at once.
+int launch_tail(ptmi_ctx* c, const RenderConst& rc, const Paths& P, StepCtl* ctl, int first, uint32_t limit) {
+  const int sa = stack_alloc_for(c);
+  const int le = std::min(sa, std::max(1, env_int("PTMI_LDS_STACK", 10)));
+  const int se = sa - le;
+  const size_t lds = (size_t)le * 2 * 64 * sizeof(int);
+  const bool noabort = c->bvh_depth < c->prm.stack_size && env_int("PTMI_NOABORT", 1) != 0;
+  const int waves_per_cu = std::max(1, std::min(32, env_int("PTMI_TAIL_WAVES_PER_CU", 16)));
+  const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>((limit + 63) / 64, (uint32_t)c->num_cus * (uint32_t)waves_per_cu));
+  HIP_TRY(c, c->d_spill.ensure(std::max<size_t>(16, (size_t)c->num_cus * 32 * (size_t)se * 64 * sizeof(int2))));  // (k_bvh's grids are no larger: one size for both)
+  unsigned long long* tot = c->d_totals.as<unsigned long long>();
+  ScopedSpan sp(c, T_TAIL);
+#define PTMI_LAUNCH_TAIL(IS, CN, MU, NA) \
+  hipLaunchKernelGGL((k_tail<IS, CN, MU, NA>), dim3(grid), dim3(64), lds, c->stream, c->S, rc, P, ctl, tot, first, limit, c->prm.stack_size, le, se, c->d_spill.as<int2>())
+#define PTMI_LAUNCH_TAIL3(IS, CN, MU)          \
+  do {                                         \
+    if (noabort) PTMI_LAUNCH_TAIL(IS, CN, MU, true); \
+    else PTMI_LAUNCH_TAIL(IS, CN, MU, false);  \
+  } while (0)
+#define PTMI_LAUNCH_TAIL2(IS, CN)                             \
+  do {                                                        \
+    if (rc.num_samples > 1) PTMI_LAUNCH_TAIL3(IS, CN, true);  \
+    else PTMI_LAUNCH_TAIL3(IS, CN, false);                    \
+  } while (0)
+  if (c->prm.importance_sampling) {
+    if (c->counters) PTMI_LAUNCH_TAIL2(true, true);
+    else PTMI_LAUNCH_TAIL2(true, false);
+  } else {
+    if (c->counters) PTMI_LAUNCH_TAIL2(false, true);
+    else PTMI_LAUNCH_TAIL2(false, false);
+  }
+#undef PTMI_LAUNCH_TAIL2
+#undef PTMI_LAUNCH_TAIL3
+#undef PTMI_LAUNCH_TAIL
+  HIP_TRY(c, hipGetLastError());
+  c->stats.tail_launches++;
   return PTMI_OK;
 }
 
@@ -754,6 +796,8 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   }
   const uint32_t sgrid = std::max<uint32_t>(1, std::min<uint32_t>((bound + kSChunk - 1) / kSChunk, (uint32_t)c->num_cus * (uint32_t)std::min(8, std::max(1, shade_bpc))));  // <= 8: the queue buffers' slack is sized for that (ensure_paths)
   unsigned long long* tot = c->d_totals.as<unsigned long long>();
+  // queues of at most this many slots are traced to the end by one k_tail launch instead of a k_bvh + k_shade pair per bounce
+  const uint32_t tail_limit = (uint32_t)std::max(0, env_int("PTMI_TAIL_LIMIT", kTailLimit));
 
   ScopedSpan whole(c, T_RENDER);
   c->batch_enqueued = true;  // from here on a failure leaves a partly traced batch behind: never retried
@@ -777,6 +821,10 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
       if (left == 0) break;
     }
     Paths P = paths_of(c, s, rc.num_samples > 1);
+    if (tail_limit > 0) {
+      int lr = launch_tail(c, rc, P, ctl + s, s == 0 ? 1 : 0, tail_limit);
+      if (lr) return lr;
+    }
     {
       int lr = launch_intersect(c, P, ctl + s, bound, false);
       if (lr) return lr;
@@ -1608,7 +1656,7 @@ int ptmi_set_counters(ptmi_ctx* c, int on) {
 }
 int ptmi_set_timing(ptmi_ctx* c, int on) {
   if (!c) return PTMI_ERR_INVALID_ARG;
-  c->timing = (on < 0 || on > 5) ? 0 : on;
+  c->timing = (on < 0 || on > 6) ? 0 : on;
   for (ptmi_ctx* q : c->peers) q->timing = c->timing;
   return PTMI_OK;
 }
@@ -1642,11 +1690,12 @@ int ptmi_get_stats(ptmi_ctx* c, ptmi_stats* out) {
     out->sphere_tests += s.sphere_tests, out->quad_tests += s.quad_tests, out->mat_fetches += s.mat_fetches;
     out->bvh_node_visits += s.bvh_node_visits, out->bvh_mat_fetches += s.bvh_mat_fetches;
     out->intersect_launches += s.intersect_launches, out->shade_launches += s.shade_launches;
-    out->generate_launches += s.generate_launches, out->accumulate_launches += s.accumulate_launches;
+    out->generate_launches += s.generate_launches, out->accumulate_launches += s.accumulate_launches, out->tail_launches += s.tail_launches;
     out->render_ms = std::max(out->render_ms, s.render_ms), out->intersect_ms = std::max(out->intersect_ms, s.intersect_ms);
     out->shade_ms = std::max(out->shade_ms, s.shade_ms), out->other_ms = std::max(out->other_ms, s.other_ms);
     out->prims_ms = std::max(out->prims_ms, s.prims_ms), out->bvh_ms = std::max(out->bvh_ms, s.bvh_ms);
     out->generate_ms = std::max(out->generate_ms, s.generate_ms), out->accumulate_ms = std::max(out->accumulate_ms, s.accumulate_ms);
+    out->tail_ms = std::max(out->tail_ms, s.tail_ms);
     out->devices += 1;
   }
   return PTMI_OK;

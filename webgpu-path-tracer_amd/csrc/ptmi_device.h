@@ -794,7 +794,42 @@ struct HitGeom {
   f3 p, n;
   bool front;
 };
-DEV HitGeom resolve_hit(const DevScene& S, f3 o, f3 d, float t, float u, float v, uint32_t prim) {
+// What resolve_hit needs of a TRIANGLE hit, fetched in one go as soon as the hit record is known (k_shade issues these loads together
+// with the material's instead of one dependent round trip after the other: barycentrics, the vertex normals, the mesh's transform id).
+struct TriFetch {
+  float2 uv;
+  float4 nA, nB, nC;
+  int gid;
+};
+DEV TriFetch tri_fetch(const DevScene& S, const float2* __restrict__ uvbuf, uint32_t slot, uint32_t prim) {
+  TriFetch f;
+  f.uv = make_float2(0.0f, 0.0f);
+  f.nA = f.nB = f.nC = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  f.gid = 0;
+  if ((prim >> 28) == K_TRI) {
+    const uint32_t idx = prim & 0x0fffffffu;
+    f.uv = uvbuf[slot];
+    const float4* tr = S.tris + 6 * (size_t)idx;
+    f.nA = tr[3], f.nB = tr[4], f.nC = tr[5];
+    f.gid = __float_as_int(S.pretri[4 * (size_t)idx + 2].w);  // = meshes[i32(nC.w)].global_id, kept in the traversal digest
+  }
+  return f;
+}
+// (k_tail holds the barycentrics in registers)
+DEV TriFetch tri_fetch_uv(const DevScene& S, float2 uv, uint32_t prim) {
+  TriFetch f;
+  f.uv = uv;
+  f.nA = f.nB = f.nC = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  f.gid = 0;
+  if ((prim >> 28) == K_TRI) {
+    const uint32_t idx = prim & 0x0fffffffu;
+    const float4* tr = S.tris + 6 * (size_t)idx;
+    f.nA = tr[3], f.nB = tr[4], f.nC = tr[5];
+    f.gid = __float_as_int(S.pretri[4 * (size_t)idx + 2].w);
+  }
+  return f;
+}
+DEV HitGeom resolve_hit(const DevScene& S, f3 o, f3 d, float t, const TriFetch& tf, uint32_t prim) {
   HitGeom g;
   uint32_t kind = prim >> 28, idx = prim & 0x0fffffffu;
   g.p = o + t * d;  // at(ray, t)
@@ -812,12 +847,9 @@ DEV HitGeom resolve_hit(const DevScene& S, f3 o, f3 d, float t, float u, float v
     g.front = dot3(d, g.n) < 0;
     if (!g.front) g.n = -g.n;
   } else {  // K_TRI, common.wgsl:224-237
-    const float4* tr = S.tris + 6 * (size_t)idx;
-    float4 nA = tr[3], nB = tr[4], nC = tr[5];
-    int gid = __float_as_int(S.pretri[4 * (size_t)idx + 2].w);  // = meshes[i32(nC.w)].global_id, fetched alongside
-    float w = 1.0f - u - v;
-    f3 nn = mk3(nA) * w + mk3(nB) * u + mk3(nC) * v;
-    g.n = norm3(mat_mul_transposed_dir(S.xforms + 8 * gid + 4, nn));
+    float w = 1.0f - tf.uv.x - tf.uv.y;
+    f3 nn = mk3(tf.nA) * w + mk3(tf.nB) * tf.uv.x + mk3(tf.nC) * tf.uv.y;
+    g.n = norm3(mat_mul_transposed_dir(S.xforms + 8 * tf.gid + 4, nn));
     g.front = dot3(d, g.n) < 0;
     if (!g.front) g.n = -g.n;
   }

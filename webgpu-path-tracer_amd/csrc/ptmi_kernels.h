@@ -516,7 +516,7 @@ DEV void end_sample_progressive(const Paths& P, uint32_t pid, f3 add) {
 // reference's progressive mode (NUM_SAMPLES = 1) compiles without it, which also frees the scalar registers the view matrix and
 // the image constants would occupy through the whole kernel.
 template <bool IS, bool MULTI>
-DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, const SlotState& st, const QuadL& L, NewState& ns) {
+DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, const SlotState& st, const TriFetch& tf, const QuadL& L, NewState& ns) {
   const uint32_t pid = __float_as_uint(st.q1.w);
   const f3 o = mk3(st.q0), d = mk3(st.q1);
   const float4 T4 = st.q2;
@@ -538,9 +538,7 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
     Material m = load_material(S, mat);
     // the chunk is sorted by this class, so `bin` is wave-uniform almost everywhere
     const int bin = (m.type == 0.0f) ? BIN_LAMBERTIAN : (m.type == 1.0f) ? BIN_MIRROR : (m.type == 2.0f) ? BIN_GLASS : (m.type == 3.0f) ? BIN_ISOTROPIC : BIN_OTHER;
-    float2 uv = make_float2(0.0f, 0.0f);
-    if ((prim >> 28) == K_TRI) uv = P.uv[st.slot];
-    HitGeom g = resolve_hit(S, o, d, st.tp.x, uv.x, uv.y, prim);
+    HitGeom g = resolve_hit(S, o, d, st.tp.x, tf, prim);
     f3 emission = m.emission;
     if (!g.front) emission = mk3(0, 0, 0);  // traceRay.wgsl:19-22
     float doSpecular;
@@ -647,9 +645,13 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
 #ifndef PTMI_SCHUNK
 #define PTMI_SCHUNK 512
 #endif
+#ifndef PTMI_REGION_DIV
+#define PTMI_REGION_DIV 16  // A/B: a block's share of the queue is claimed in this many regions (x4: every wave claims its own)
+#endif
 #ifndef PTMI_MISS_SHORTCUT
 #define PTMI_MISS_SHORTCUT 1
 #endif
+constexpr int kTailLimit = 4 << 20;  // k_tail takes a step's queue over when it is at most this long (slots)
 constexpr bool kMissShortcut = PTMI_MISS_SHORTCUT != 0;  // A/B: settle definite misses in k_shade's flush phase
 constexpr int kSChunk = PTMI_SCHUNK;  // slots a k_shade block sorts, shades and compacts at a time
 
@@ -675,7 +677,7 @@ DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, St
   const uint32_t n = ctl->n_rays;
   // region size: a block handles about n / gridDim slots per launch; 1/16 of that per claim keeps both the
   // number of atomics and the holes left at the end (at most one region per block) small
-  const uint32_t region = max((uint32_t)kSChunk, ((n / gridDim.x / 16u) + 511u) & ~511u);
+  const uint32_t region = max((uint32_t)kSChunk, ((n / gridDim.x / (uint32_t)PTMI_REGION_DIV) + 511u) & ~511u);
   const uint32_t wregion = region / (kBlock / 64);  // every wave fills output regions of its own (>= 128 slots): no barrier, no serial section in the flush phase
   uint32_t w_cur = 0, w_rend = 0;                   // this wave's current output region [w_cur, w_rend) of the next queue (wave-uniform)
   // The waves' FIRST regions come from one claim per block, made by whichever wave needs a region first; the others pick their quarter
@@ -764,7 +766,8 @@ DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, St
         ns.bounce = 0, ns.rng = 0, ns.pid = 0;
         if (k < nvalid) {
           const SlotState st = load_slot(P, base + s_sorted[k], first != 0);
-          survive = shade_one<IS, MULTI>(S, rc, P, st, L, ns);
+          const TriFetch tf = tri_fetch(S, P.uv, st.slot, __float_as_uint(st.tp.y));  // (issued ahead of the material's loads, consumed after them)
+          survive = shade_one<IS, MULTI>(S, rc, P, st, tf, L, ns);
         }
         stage(survive, ns);
       }
@@ -780,7 +783,10 @@ DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, St
         if (j < m) {
           const SlotState st = load_slot(P, base + j, first != 0);
           valid = __float_as_uint(st.q1.w) != PID_HOLE;
-          if (valid) survive = shade_one<IS, MULTI>(S, rc, P, st, L, ns);
+          if (valid) {
+            const TriFetch tf = tri_fetch(S, P.uv, st.slot, __float_as_uint(st.tp.y));  // (issued ahead of the material's loads, consumed after them)
+            survive = shade_one<IS, MULTI>(S, rc, P, st, tf, L, ns);
+          }
         }
         my_valid += (uint32_t)__popcll(__ballot(valid));
         stage(survive, ns);
@@ -907,6 +913,123 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) 
   shade_body<false, SORT, COUNT, false>(S, rc, P, ctl, heads, totals, first);
 }
 
+// k_tail — a SHORT queue traced to the end in one launch: every lane takes a path and runs ray_color's loop for it (hitScene part 2 on
+// LDS stacks with the state machine of k_bvh, ray_color's body by shade_one, hitScene part 1 for the new ray) until the path ends —
+// the reference's own megakernel shape, used where the wavefront pipeline has run out of parallelism: the last bounces of a batch (3 %
+// of configs[1]'s rays took 11 % of its launches and 0.8 ms of 15), a lone interactive frame, and the long thin tail of the reference's
+// default MAX_BOUNCES = 100.  Launched in front of every step's k_bvh; declines (all blocks return at once) unless 0 < n_rays <= limit;
+// when it has run, the block that finishes last zeroes the queue length, so the step's k_bvh / k_shade and every later step find nothing.
+// Same per-ray arithmetic and visit order as the wavefront kernels (the same device functions), same counters and tallies.
+template <bool IS, bool COUNT, bool MULTI, bool NOABORT>
+__global__ __launch_bounds__(64) void k_tail(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, unsigned long long* __restrict__ totals, int first, uint32_t limit,
+                                             int stack_size, int lds_entries, int spill_entries, int2* __restrict__ spill) {
+  const uint32_t n = ctl->n_rays;
+  if (n == 0u || n > limit) return;
+  extern __shared__ int lds_stack[];
+  const int lane = lane_id();
+  LaneStack2 stk;
+  stk.lds = (lds_v2i_t*)lds_stack + lane;
+  stk.spill = spill + (size_t)blockIdx.x * (size_t)spill_entries * 64 + lane;
+  stk.lds_entries = lds_entries;
+  const QuadL L = load_light(S);
+  Counters cn = {0, 0, 0, 0, 0}, cb = {0, 0, 0, 0, 0};  // hitScene part 1 / part 2 (k_bvh's share is reported separately)
+  uint32_t tally = 0;  // hitScene invocations
+  const uint32_t root = __float_as_uint(S.root_lo.w);
+  const uint32_t root_node = (root & REF_LEAF) ? root : (root & REF_IDX);
+#pragma unroll 1
+  for (uint32_t base = blockIdx.x * 64u; base < n; base += gridDim.x * 64u) {
+    const uint32_t slot = base + (uint32_t)lane;
+    SlotState st;
+    st.q0 = st.q1 = st.q2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    st.tp = make_float2(0.0f, 0.0f);
+    st.hitmat = HITMAT_HOLE, st.slot = slot;
+    bool alive = false;
+    if (slot < n) {
+      st = load_slot(P, slot, first != 0);
+      alive = __float_as_uint(st.q1.w) != PID_HOLE;
+    }
+    float2 uv = make_float2(0.0f, 0.0f);  // (the queue comes from k_generate / k_shade: no triangle hit in it yet)
+#pragma unroll 1
+    while (__ballot(alive) != 0ull) {
+      // ---- hitScene part 2 (hitRay.wgsl:42-110) for the lanes whose ray entered the root box ----
+      const bool flagged = alive && (st.hitmat & HITMAT_BVH) != 0u;
+      if (__ballot(flagged) != 0ull) {
+        uint32_t node = flagged ? root_node : N_DONE;
+        int sp = 0;
+        const f3 o = mk3(st.q0), d = mk3(st.q1);
+        const f3 inv = rcp3_exact_il(d);
+        const uint32_t negmask = (d.x < 0 ? 1u : 0u) | (d.y < 0 ? 2u : 0u) | (d.z < 0 ? 4u : 0u);
+        float ct = st.tp.x;
+        ObjRay orr;
+        orr.mesh = -1;
+        orr.o = orr.d = o;
+        TriHit hit = {0.0f, 0.0f, 0u, 0u};
+#pragma unroll 1
+        while (__ballot(node != N_DONE) != 0ull) {
+          if ((int)node < 0) {
+            const int2 lc = (node & REF_MULTI) ? S.leaf_table[node & REF_IDX] : make_int2((int)(node & REF_IDX), 1);
+            for (int j = 0; j < lc.y; j++) {
+              const float4* rec = S.pretri + 4 * (size_t)(lc.x + j);
+              const float4 g0 = rec[0], g1 = rec[1], g2 = rec[2], g3 = rec[3];
+              tri_test2<COUNT>(S, lc.x + j, g0, g1, g2, g3, o, d, orr, ct, hit, cb);
+            }
+            node = pop_until_pass2(stk, sp, ct, cb, COUNT);
+          }
+          if (node < N_INNER_LIMIT) {
+            const float4* rec = S.pairs + 4 * (size_t)node;
+            const float4 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3v = rec[3];
+            node = inner_step2<COUNT, NOABORT>(f0, f1, f2, f3v, o, inv, S.tmin, negmask, ct, stack_size, stk, sp, cb);
+            if (node == N_POP) node = pop_until_pass2(stk, sp, ct, cb, COUNT);
+          }
+        }
+        if (hit.prim != 0u) {  // a triangle beat what part 1 had found
+          st.tp = make_float2(ct, __uint_as_float(hit.prim));
+          uv = make_float2(hit.u, hit.v);
+          st.hitmat = hit.mat;
+        }
+      }
+      // ---- ray_color's loop body (traceRay.wgsl:10-80) ----
+      NewState ns;
+      ns.o = ns.d = ns.T = mk3(0, 0, 0);
+      ns.bounce = 0, ns.rng = 0, ns.pid = 0;
+      bool survive = false;
+      if (alive) {
+        tally++;
+        const TriFetch tf = tri_fetch_uv(S, uv, __float_as_uint(st.tp.y));
+        survive = shade_one<IS, MULTI>(S, rc, P, st, tf, L, ns);
+      }
+      alive = survive;
+      // ---- hitScene part 1 for the new ray (hitRay.wgsl:6-54) ----
+      if (alive) {
+        uint32_t rng = ns.rng, hm;
+        float2 tp;
+        prims_for_ray<COUNT>(S, ns.o, ns.d, rng, tp, hm, cn);
+        if (kMissShortcut && !MULTI && hm == HITMAT_MISS) {  // traceRay.wgsl:12-16, as in k_shade's flush phase
+          end_sample_progressive(P, ns.pid, mk3(rc.bg[0], rc.bg[1], rc.bg[2]) * ns.T);
+          tally++;
+          alive = false;
+        } else {
+          st.q0 = make_float4(ns.o.x, ns.o.y, ns.o.z, __uint_as_float(rng));
+          st.q1 = make_float4(ns.d.x, ns.d.y, ns.d.z, __uint_as_float(ns.pid));
+          st.q2 = make_float4(ns.T.x, ns.T.y, ns.T.z, __int_as_float(ns.bounce));
+          st.tp = tp;
+          st.hitmat = hm;
+        }
+      }
+    }
+  }
+  for (int off2 = 32; off2 > 0; off2 >>= 1) tally += __shfl_down(tally, off2, 64);
+  if (lane == 0 && tally) atomicAdd(tally_line(totals, blockIdx.x), tally);
+  if (COUNT) {
+    reduce_counters(cn, totals, false);
+    reduce_counters(cb, totals, true);
+  }
+  if (lane == 0) {  // whoever finishes last closes the queue (every block has read its length by then)
+    __threadfence();
+    if (atomicAdd(&ctl->pad[0], 1u) == gridDim.x - 1u) ctl->n_rays = 0u;
+  }
+}
+
 // main.wgsl:22-27 for the frame slots [f_begin, f_end) of the batch, in frame order; the call that folds slot 0 also
 // tallies the batch's rays/paths.  (ptmi_render_frame's render-ahead folds one slot per call.)
 __global__ __launch_bounds__(kBlock) void k_accumulate(RenderConst rc, Paths P, float4* __restrict__ fb, int n_steps,
@@ -993,9 +1116,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_hits(DevScene S, Paths P, ui
   o.hit = (prim >> 28) != K_NONE;
   if (o.hit) {
     float4 r0 = P.in.q0[i], r1 = P.in.q1[i];
-    float2 uv = make_float2(0.0f, 0.0f);
-    if ((prim >> 28) == K_TRI) uv = P.uv[i];
-    HitGeom g = resolve_hit(S, mk3(r0), mk3(r1), h.x, uv.x, uv.y, prim);
+    HitGeom g = resolve_hit(S, mk3(r0), mk3(r1), h.x, tri_fetch(S, P.uv, i, prim), prim);
     o.t = h.x;
     o.p[0] = g.p.x, o.p[1] = g.p.y, o.p[2] = g.p.z;
     o.normal[0] = g.n.x, o.normal[1] = g.n.y, o.normal[2] = g.n.z;

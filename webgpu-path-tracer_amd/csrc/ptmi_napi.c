@@ -500,6 +500,8 @@ static napi_value js_stats(napi_env env, napi_callback_info info) {
   set_f64(env, o, "bvh_ms", s.bvh_ms);
   set_f64(env, o, "generate_ms", s.generate_ms);
   set_f64(env, o, "accumulate_ms", s.accumulate_ms);
+  set_f64(env, o, "tail_ms", s.tail_ms);
+  set_f64(env, o, "tail_launches", (double)s.tail_launches);
   set_f64(env, o, "devices", (double)s.devices);
   set_f64(env, o, "bvh_node_visits", (double)s.bvh_node_visits);
   set_f64(env, o, "bvh_mat_fetches", (double)s.bvh_mat_fetches);

@@ -35,7 +35,7 @@ class Stats(ctypes.Structure):
         "rays", "paths", "node_visits", "tri_tests", "sphere_tests", "quad_tests", "mat_fetches", "frames",
         "intersect_launches", "shade_launches", "bvh_node_visits", "bvh_mat_fetches")] + [
         (n, ctypes.c_double) for n in ("render_ms", "intersect_ms", "shade_ms", "other_ms", "prims_ms", "bvh_ms", "generate_ms", "accumulate_ms")] + [
-        (n, ctypes.c_uint64) for n in ("generate_launches", "accumulate_launches", "devices")]
+        (n, ctypes.c_uint64) for n in ("generate_launches", "accumulate_launches", "devices")] + [("tail_ms", ctypes.c_double), ("tail_launches", ctypes.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
