@@ -645,13 +645,16 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
 #ifndef PTMI_SCHUNK
 #define PTMI_SCHUNK 512
 #endif
+#ifndef PTMI_SHADE_WAVE
+#define PTMI_SHADE_WAVE 1  // A/B: 0 = the unsorted variants run the block version (three barriers per chunk) like the sorted ones
+#endif
 #ifndef PTMI_REGION_DIV
 #define PTMI_REGION_DIV 16  // A/B: a block's share of the queue is claimed in this many regions (x4: every wave claims its own)
 #endif
 #ifndef PTMI_MISS_SHORTCUT
 #define PTMI_MISS_SHORTCUT 1
 #endif
-constexpr int kTailLimit = 4 << 20;  // k_tail takes a step's queue over when it is at most this long (slots)
+constexpr int kTailLimit = 2 << 20;  // k_tail takes a step's queue over when it is at most this long (slots): a lone 1080p frame fits; 4 Mi already loses on configs[1]'s step 4
 constexpr bool kMissShortcut = PTMI_MISS_SHORTCUT != 0;  // A/B: settle definite misses in k_shade's flush phase
 constexpr int kSChunk = PTMI_SCHUNK;  // slots a k_shade block sorts, shades and compacts at a time
 
@@ -900,17 +903,168 @@ DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, St
   if (COUNT) reduce_counters(cn, totals, false);
 }
 
+// ray_color's loop body for scenes with ONE material class (no sort): every WAVE on its own, no barrier inside the loop.  A wave shades
+// the same 64-slot groups of the block's chunks as in shade_body, stages its survivors in an LDS ring of its own (128 entries) and runs a
+// flush pass — hitScene part 1 for 64 new rays, all lanes busy — whenever 64 are waiting; what is left goes out in one last, partial pass.
+// (shade_body's three barriers per chunk had every wave wait for the block's slowest three times per 128 slots of its own work.)
+template <bool IS, bool COUNT, bool MULTI>
+DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads,
+                         unsigned long long* __restrict__ totals, int first) {
+  reset_heads(heads);
+  constexpr uint32_t kRing = 128, kWaves = kBlock / 64;
+  static_assert((size_t)kWaves * kRing == (size_t)kSChunk, "the rings take the LDS the block version's staging arrays take");
+  __shared__ float4 s_q0[kWaves * kRing], s_q1[kWaves * kRing], s_q2[kWaves * kRing];
+  constexpr uint32_t kR0Empty = 0xffffffffu, kR0Busy = 0xfffffffeu, kR0Full = 0xfffffffdu;
+  __shared__ uint32_t s_region0;  // the waves' first regions: one claim per block (see shade_body)
+  if (threadIdx.x == 0) s_region0 = kR0Empty;
+  __syncthreads();
+  const QuadL L = load_light(S);
+  const int lane = lane_id();
+  const uint32_t wv = threadIdx.x >> 6;
+  float4 *const r0 = s_q0 + wv * kRing, *const r1 = s_q1 + wv * kRing, *const r2 = s_q2 + wv * kRing;
+  const uint32_t n = ctl->n_rays;
+  const uint32_t region = max((uint32_t)kSChunk, ((n / gridDim.x / (uint32_t)PTMI_REGION_DIV) + 511u) & ~511u);
+  const uint32_t wregion = region / kWaves;
+  uint32_t w_cur = 0, w_rend = 0;  // this wave's current output region of the next queue (wave-uniform)
+  uint32_t head = 0, cnt = 0;      // the ring: `cnt` survivors wait from entry `head` on (wave-uniform)
+  uint32_t my_valid = 0, my_missed = 0;
+  Counters cn = {0, 0, 0, 0, 0};
+  // hitScene part 1 for the first `take` (<= 64) waiting survivors, one per lane; settles definite misses, places the others in the next queue
+  auto flush_pass = [&](uint32_t take) {
+    const uint32_t q = (head + (uint32_t)lane) & (kRing - 1u);
+    bool keep = false;
+    float2 tp = make_float2(0.0f, 0.0f);
+    uint32_t hm = 0u, rng = 0u;
+    if ((uint32_t)lane < take) {
+      const float4 a0 = r0[q], a1 = r1[q];
+      rng = __float_as_uint(a0.w);
+      prims_for_ray<COUNT>(S, mk3(a0), mk3(a1), rng, tp, hm, cn);
+      if (kMissShortcut && !MULTI && hm == HITMAT_MISS) {  // traceRay.wgsl:12-16 (see shade_body)
+        end_sample_progressive(P, __float_as_uint(a1.w), mk3(rc.bg[0], rc.bg[1], rc.bg[2]) * mk3(r2[q]));
+      } else {
+        keep = true;
+      }
+    }
+    const uint64_t km = __ballot(keep);
+    const uint32_t kept = (uint32_t)__popcll(km);
+    my_missed += take - kept;
+    if (kept) {
+      const uint32_t rank = lanes_below(km);
+      const uint32_t b0 = w_cur, n0 = min(kept, w_rend - w_cur);
+      uint32_t b1 = 0xffffffffu;
+      w_cur += n0;
+      if (kept > n0) {  // claim the wave's next region for the rest
+        uint32_t nb = 0;
+        bool full;
+        if (w_rend == 0u) {  // the wave's first region: its quarter of the block's claim
+          if (lane == 0) nb = atomicCAS(&s_region0, kR0Empty, kR0Busy);
+          nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+          if (nb == kR0Empty) {
+            if (lane == 0) {
+              nb = atomicAdd(&ctl[1].n_rays, region);
+              if (nb + region > P.cap) {  // cannot happen with the host's sizing
+                atomicAdd(&totals[15], 1ull);
+                atomicSub(&ctl[1].n_rays, region);
+                nb = kR0Full;
+              }
+              atomicExch(&s_region0, nb);
+            }
+            nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+          } else {
+            while (nb == kR0Busy) {
+              __builtin_amdgcn_s_sleep(8);
+              if (lane == 0) nb = atomicAdd(&s_region0, 0u);
+              nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+            }
+          }
+          full = nb == kR0Full;
+          nb += wv * wregion;
+        } else {
+          if (lane == 0) nb = atomicAdd(&ctl[1].n_rays, wregion);
+          nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+          full = nb + wregion > P.cap;
+          if (full && lane == 0) {
+            atomicAdd(&totals[15], 1ull);
+            atomicSub(&ctl[1].n_rays, wregion);
+          }
+        }
+        if (!full) {  // (full: what still fitted is written, the rest is dropped and flagged — see shade_body)
+          b1 = nb;
+          w_cur = nb + (kept - n0);
+          w_rend = nb + wregion;
+        }
+      }
+      if (keep && (rank < n0 || b1 != 0xffffffffu)) {
+        const uint32_t dst = (rank < n0) ? (b0 + rank) : (b1 + (rank - n0));
+        float4 a0 = r0[q];
+        a0.w = __uint_as_float(rng);
+        P.out.q0[dst] = a0;
+        P.out.q1[dst] = r1[q];
+        P.out.q2[dst] = r2[q];
+        P.hout.tp[dst] = tp;
+        P.hout.mat[dst] = hm;
+      }
+    }
+    head = (head + take) & (kRing - 1u);
+    cnt -= take;
+  };
+  for (uint32_t base = blockIdx.x * (uint32_t)kSChunk; base < n; base += gridDim.x * (uint32_t)kSChunk) {
+    const uint32_t m = min((uint32_t)kSChunk, n - base);
+#pragma unroll 1
+    for (uint32_t j0 = wv * 64u; j0 < m; j0 += kBlock) {
+      const uint32_t j = j0 + (uint32_t)lane;
+      bool survive = false, valid = false;
+      NewState ns;
+      ns.o = ns.d = ns.T = mk3(0, 0, 0);
+      ns.bounce = 0, ns.rng = 0, ns.pid = 0;
+      if (j < m) {
+        const SlotState st = load_slot(P, base + j, first != 0);
+        valid = __float_as_uint(st.q1.w) != PID_HOLE;
+        if (valid) {
+          const TriFetch tf = tri_fetch(S, P.uv, st.slot, __float_as_uint(st.tp.y));  // (issued ahead of the material's loads, consumed after them)
+          survive = shade_one<IS, MULTI>(S, rc, P, st, tf, L, ns);
+        }
+      }
+      my_valid += (uint32_t)__popcll(__ballot(valid));
+      const uint64_t mk = __ballot(survive);
+      if (survive) {
+        const uint32_t q = (head + cnt + lanes_below(mk)) & (kRing - 1u);
+        r0[q] = make_float4(ns.o.x, ns.o.y, ns.o.z, __uint_as_float(ns.rng));
+        r1[q] = make_float4(ns.d.x, ns.d.y, ns.d.z, __uint_as_float(ns.pid));
+        r2[q] = make_float4(ns.T.x, ns.T.y, ns.T.z, __int_as_float(ns.bounce));
+      }
+      cnt += (uint32_t)__popcll(mk);
+      if (cnt >= 64u) flush_pass(64u);
+    }
+  }
+  if (cnt) flush_pass(cnt);
+  if (MULTI) my_missed = 0;  // (no path ends in the flush phase then)
+  if (lane == 0 && my_missed + my_valid) atomicAdd(tally_line(totals, blockIdx.x), my_missed + my_valid);
+  __syncthreads();  // the block's claim, if any wave made one, is in s_region0 now
+  if (w_rend == 0u && s_region0 < kR0Full) {  // never needed a region: all of this wave's quarter of the block's claim becomes holes
+    w_cur = s_region0 + wv * wregion;
+    w_rend = w_cur + wregion;
+  }
+  for (uint32_t i = w_cur + (uint32_t)lane; i < w_rend; i += 64u) {
+    reinterpret_cast<uint32_t*>(P.out.q1 + i)[3] = PID_HOLE;
+    P.hout.mat[i] = HITMAT_HOLE;
+  }
+  if (COUNT) reduce_counters(cn, totals, false);
+}
+
 // The kernel proper, twice: the progressive-mode variants without importance sampling fit 80 VGPRs — 6 waves per SIMD, which this
 // latency-bound kernel turns into throughput (round 3: 5 -> 6 blocks per CU, -8 %) —, the others need up to 96 (5 waves; at 80 they spill).
 template <bool IS, bool SORT, bool COUNT, bool MULTI>
 __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads,
                                                                   unsigned long long* __restrict__ totals, int first) {
-  shade_body<IS, SORT, COUNT, MULTI>(S, rc, P, ctl, heads, totals, first);
+  if (SORT || PTMI_SHADE_WAVE == 0) shade_body<IS, SORT, COUNT, MULTI>(S, rc, P, ctl, heads, totals, first);
+  else shade_body_wave<IS, COUNT, MULTI>(S, rc, P, ctl, heads, totals, first);
 }
 template <bool SORT, bool COUNT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_shade6(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl,
                                                                                                 uint32_t* __restrict__ heads, unsigned long long* __restrict__ totals, int first) {
-  shade_body<false, SORT, COUNT, false>(S, rc, P, ctl, heads, totals, first);
+  if (SORT || PTMI_SHADE_WAVE == 0) shade_body<false, SORT, COUNT, false>(S, rc, P, ctl, heads, totals, first);
+  else shade_body_wave<false, COUNT, false>(S, rc, P, ctl, heads, totals, first);
 }
 
 // k_tail — a SHORT queue traced to the end in one launch: every lane takes a path and runs ray_color's loop for it (hitScene part 2 on
