@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True, params=["wavefront", "mixed", "tail"])
 def pipeline(request, monkeypatch):
     """Every case three times: through the wavefront kernels alone (k_generate, k_bvh, k_shade per bounce), with the library's default
-    hand-over (k_tail traces a step's queue to the end once it is at most 2 Mi slots long: the small cases never leave k_tail, the
-    full-size ones switch in mid-batch), and with k_tail taking every queue whole from step 0.  PTMI_TAIL_LIMIT is read per render."""
+    hand-over (k_tail traces a queue to the end once it is at most 2 Mi slots long at step 0, 512 Ki later: the small cases never leave
+    k_tail, the full-size ones switch in mid-batch), and with k_tail taking every queue whole from step 0.  PTMI_TAIL_LIMIT is read per render."""
     if request.param == "wavefront":
         monkeypatch.setenv("PTMI_TAIL_LIMIT", "0")
     elif request.param == "tail":

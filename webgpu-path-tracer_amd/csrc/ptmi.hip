@@ -797,7 +797,10 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   const uint32_t sgrid = std::max<uint32_t>(1, std::min<uint32_t>((bound + kSChunk - 1) / kSChunk, (uint32_t)c->num_cus * (uint32_t)std::min(8, std::max(1, shade_bpc))));  // <= 8: the queue buffers' slack is sized for that (ensure_paths)
   unsigned long long* tot = c->d_totals.as<unsigned long long>();
   // queues of at most this many slots are traced to the end by one k_tail launch instead of a k_bvh + k_shade pair per bounce
-  const uint32_t tail_limit = (uint32_t)std::max(0, env_int("PTMI_TAIL_LIMIT", kTailLimit));
+  // (a whole small batch — a lone 1080p frame — at step 0; later steps hand over only their thin ends: on deep trees a lane-per-path
+  // wave waits for its longest traversal, and the wavefront kernels with their lane refill stay ahead down to ~0.5 Mi slots)
+  const int tail_env = env_int("PTMI_TAIL_LIMIT", -1);
+  const uint32_t tail_limit_first = (uint32_t)(tail_env >= 0 ? tail_env : kTailLimitFirst), tail_limit_later = (uint32_t)(tail_env >= 0 ? tail_env : kTailLimitLater);
 
   ScopedSpan whole(c, T_RENDER);
   c->batch_enqueued = true;  // from here on a failure leaves a partly traced batch behind: never retried
@@ -821,7 +824,7 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
       if (left == 0) break;
     }
     Paths P = paths_of(c, s, rc.num_samples > 1);
-    if (tail_limit > 0) {
+    if (const uint32_t tail_limit = s == 0 ? tail_limit_first : tail_limit_later) {
       int lr = launch_tail(c, rc, P, ctl + s, s == 0 ? 1 : 0, tail_limit);
       if (lr) return lr;
     }

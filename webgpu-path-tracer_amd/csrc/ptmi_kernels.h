@@ -654,7 +654,8 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
 #ifndef PTMI_MISS_SHORTCUT
 #define PTMI_MISS_SHORTCUT 1
 #endif
-constexpr int kTailLimit = 2 << 20;  // k_tail takes a step's queue over when it is at most this long (slots): a lone 1080p frame fits; 4 Mi already loses on configs[1]'s step 4
+constexpr int kTailLimitFirst = 2 << 20, kTailLimitLater = 512 << 10;  // k_tail takes a queue over when it is at most this long (slots): at step 0 (a lone 1080p frame fits) / later
+constexpr int kTailRefill = 16;  // k_tail: idle lanes before a wave takes new paths
 constexpr bool kMissShortcut = PTMI_MISS_SHORTCUT != 0;  // A/B: settle definite misses in k_shade's flush phase
 constexpr int kSChunk = PTMI_SCHUNK;  // slots a k_shade block sorts, shades and compacts at a time
 
@@ -1090,21 +1091,44 @@ __global__ __launch_bounds__(64) void k_tail(DevScene S, RenderConst rc, Paths P
   uint32_t tally = 0;  // hitScene invocations
   const uint32_t root = __float_as_uint(S.root_lo.w);
   const uint32_t root_node = (root & REF_LEAF) ? root : (root & REF_IDX);
+  // Lanes whose path has ended take the next slots of the wave's current 64-slot group (groups are dealt round-robin to the waves) once
+  // kTailRefill of them are idle: a wave keeps its lanes busy across paths of different lengths instead of waiting for its longest one.
+  SlotState st;
+  st.q0 = st.q1 = st.q2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  st.tp = make_float2(0.0f, 0.0f);
+  st.hitmat = HITMAT_HOLE, st.slot = 0;
+  bool alive = false;
+  float2 uv = make_float2(0.0f, 0.0f);  // barycentrics of the lane's triangle hit (the queue comes from k_generate / k_shade: none in it yet)
+  uint32_t gnext = blockIdx.x, gbase = 0, pos = 64;  // next group to open; the open group's first slot and how many of its slots are taken
 #pragma unroll 1
-  for (uint32_t base = blockIdx.x * 64u; base < n; base += gridDim.x * 64u) {
-    const uint32_t slot = base + (uint32_t)lane;
-    SlotState st;
-    st.q0 = st.q1 = st.q2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    st.tp = make_float2(0.0f, 0.0f);
-    st.hitmat = HITMAT_HOLE, st.slot = slot;
-    bool alive = false;
-    if (slot < n) {
-      st = load_slot(P, slot, first != 0);
-      alive = __float_as_uint(st.q1.w) != PID_HOLE;
+  for (;;) {
+    uint64_t am = __ballot(alive);
+    const uint32_t nidle = 64u - (uint32_t)__popcll(am);
+    if (nidle >= (uint32_t)kTailRefill || am == 0ull) {
+      if (pos == 64u && gnext * 64u < n) {
+        gbase = gnext * 64u;
+        gnext += gridDim.x;
+        pos = 0;
+      }
+      if (pos < 64u) {
+        const uint32_t take = min(nidle, 64u - pos), rank = lanes_below(~am);
+        if (!alive && rank < take) {
+          const uint32_t slot = gbase + pos + rank;
+          if (slot < n) {
+            st = load_slot(P, slot, first != 0);
+            alive = __float_as_uint(st.q1.w) != PID_HOLE;
+            uv = make_float2(0.0f, 0.0f);
+          }
+        }
+        pos += take;
+        am = __ballot(alive);
+      }
     }
-    float2 uv = make_float2(0.0f, 0.0f);  // (the queue comes from k_generate / k_shade: no triangle hit in it yet)
-#pragma unroll 1
-    while (__ballot(alive) != 0ull) {
+    if (am == 0ull) {
+      if (pos == 64u && gnext * 64u >= n) break;  // nothing in flight, nothing left to take
+      continue;
+    }
+    {
       // ---- hitScene part 2 (hitRay.wgsl:42-110) for the lanes whose ray entered the root box ----
       const bool flagged = alive && (st.hitmat & HITMAT_BVH) != 0u;
       if (__ballot(flagged) != 0ull) {
