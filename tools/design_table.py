@@ -26,7 +26,7 @@ rows.append("| Mrays/s (Mpaths/s) | " + " | ".join("**%.0f** (%.0f)" % (D[w]["va
 spp = {"c2": "64 spp", "c3": "256 spp", "c4": "512 spp", "c5": "128 spp"}
 rows.append("| ms per step | " + " | ".join("%.1f (%s)" % (D[w]["ms_per_step"], spp[w]) for w in cols) + " |")
 rows.append("| node visits / triangle tests per ray | " + " | ".join("%.1f / %.2f" % (D[w]["roofline"]["work_per_ray"]["node_visits"], D[w]["roofline"]["work_per_ray"]["tri_tests"]) for w in cols) + " |")
-rows.append("| ms per step: generate / bvh / shade / accumulate | " + " | ".join(" / ".join(f(k(w, n)["ms_per_step"], 2 if k(w, n)["ms_per_step"] < 100 else 0) for n in ("k_generate", "k_bvh", "k_shade", "k_accumulate")) for w in cols) + " |")
+rows.append("| ms per step: generate / bvh / shade / tail / accumulate | " + " | ".join(" / ".join(f(k(w, n)["ms_per_step"], 2 if k(w, n)["ms_per_step"] < 100 else 0) for n in ("k_generate", "k_bvh", "k_shade", "k_tail", "k_accumulate")) for w in cols) + " |")
 rows.append("| dominant kernel: bound, `frac` | " + " | ".join("`%s`: %s **%.2f**" % (D[w]["roofline"]["kernel"], {"valu_issue": "VALU issue (upper bound)", "l1_gather": "L1 gather", "hbm": "HBM"}[D[w]["roofline"]["bound"]], D[w]["roofline"]["frac"]) for w in cols) + " |")
 rows.append("| the same kernel: at 2.4 GHz / integer at 3 cycles / lane-weighted | " + " | ".join("%s / %s / %s" % (f(D[w]["roofline"].get("frac_at_2p4_ghz")), f(D[w]["roofline"].get("valu_busy_frac_int_at_3")), f(D[w]["roofline"].get("lane_weighted_frac"))) for w in cols) + " |")
 rows.append("| `k_bvh`: L1 gather / VALU busy (≤) / fabric bytes ÷ 8 TB/s / active lanes / waves parked on memory | " + " | ".join("%s / %s / %s / %s / %s" % (f(k(w, "k_bvh").get("l1_gather_frac")), f(k(w, "k_bvh").get("valu_busy_frac")), f(k(w, "k_bvh").get("hbm_frac")), f(k(w, "k_bvh").get("active_lane_frac")), f(k(w, "k_bvh").get("wave_wait_frac"))) for w in cols) + " |")
