@@ -531,6 +531,8 @@ uint32_t count_local(uint32_t npix, int rank, int world, int tile) {
   return (uint32_t)n;
 }
 
+Paths paths_of(ptmi_ctx* c, int step, bool with_pixsum);
+
 int ensure_paths(ptmi_ctx* c, size_t npaths, int n_ctl, bool need_pixsum) {
   if (npaths > c->path_cap) {
     // A queue holds at most `npaths` paths plus the holes of k_shade's output regions: at most one region per block
@@ -552,6 +554,61 @@ int ensure_paths(ptmi_ctx* c, size_t npaths, int n_ctl, bool need_pixsum) {
     c->path_cap = npaths;
     c->slot_cap = slots;
     c->pixsum_alloc = false;
+    // Where the driver puts the queue arrays decides how often their streams meet in the same HBM channels: k_shade runs up to 12 % slower
+    // in some contexts than in others, for their whole life (DESIGN.md §4 "placement").  So for batches worth the trouble (>= 4 Mi slots): allocate
+    // up to PTMI_PLACEMENT_TRIES (4) sets, time the step's access pattern on each (k_placement_probe, ~30 ms per set), keep the fastest.  Two sets
+    // exist at a time; an extra allocation that fails just ends the search.
+    const int tries = getenv("PTMI_PLACEMENT_TRIES") ? atoi(getenv("PTMI_PLACEMENT_TRIES")) : 4;
+    // (sets of more than 32 GB are taken as they come: allocating and releasing 76 GB three more times costs seconds, and the long launches of
+    // such batches showed no placement effect — configs[2] at 256 spp)
+    if (tries > 1 && slots >= ((size_t)1 << 22) && slots * 120 <= ((size_t)32 << 30)) {
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      HIP_TRY(c, hipEventCreate(&e0));
+      HIP_TRY(c, hipEventCreate(&e1));
+      const uint32_t pn = (uint32_t)std::min<size_t>(slots, (size_t)1 << 26);
+      auto score = [&](float* ms) -> hipError_t {
+        float total = 0.0f;
+        for (int rep = 0; rep < 3; rep++) {  // (the first pass pages the buffers in: not counted)
+          for (int dir = 0; dir < 2; dir++) {
+            Paths P = paths_of(c, dir, false);
+            if (hipError_t e = hipEventRecord(e0, c->stream)) return e;
+            hipLaunchKernelGGL(k_placement_probe, dim3((unsigned)c->num_cus * 8), dim3(kBlock), 0, c->stream, P, pn);
+            if (hipError_t e = hipEventRecord(e1, c->stream)) return e;
+            if (hipError_t e = hipEventSynchronize(e1)) return e;
+            float t = 0.0f;
+            if (hipError_t e = hipEventElapsedTime(&t, e0, e1)) return e;
+            if (rep) total += t;
+          }
+        }
+        *ms = total;
+        return hipSuccess;
+      };
+      float best = 0.0f;
+      HIP_TRY(c, score(&best));
+      if (getenv("PTMI_DEBUG_PLACEMENT")) fprintf(stderr, "ptmi placement: set 0 %.3f ms\n", best);
+      DBuf* mine[10] = {&c->d_q0[0], &c->d_q0[1], &c->d_q1[0], &c->d_q1[1], &c->d_q2[0], &c->d_q2[1], &c->d_tp[0], &c->d_tp[1], &c->d_hm[0], &c->d_hm[1]};
+      const size_t width[10] = {16, 16, 16, 16, 16, 16, 8, 8, 4, 4};
+      for (int t = 1; t < tries; t++) {
+        DBuf cand[10];
+        bool ok = true;
+        for (int k = 0; k < 10 && ok; k++) ok = cand[k].ensure(slots * width[k]) == hipSuccess;
+        float ms = 0.0f;
+        if (ok) {
+          for (int k = 0; k < 10; k++) std::swap(*mine[k], cand[k]);  // (cand now holds the best set so far)
+          ok = score(&ms) == hipSuccess;
+          if (getenv("PTMI_DEBUG_PLACEMENT")) fprintf(stderr, "ptmi placement: set %d %.3f ms\n", t, ms);
+          if (!ok || ms >= best) {
+            for (int k = 0; k < 10; k++) std::swap(*mine[k], cand[k]);  // keep the old one
+          } else {
+            best = ms;
+          }
+        }
+        for (int k = 0; k < 10; k++) cand[k].release();
+        if (!ok) break;
+      }
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+    }
   }
   if (need_pixsum && !c->pixsum_alloc) {
     HIP_TRY(c, c->d_pixsum.ensure(c->path_cap * 16));
