@@ -132,7 +132,7 @@ struct ptmi_ctx {
   bool bvh_on_device = false;
   size_t bvh_dev_prims = 0;  // triangles the device-resident tree was built over
   int bvh_dev_depth = 0;
-  DBuf d_spheres, d_sphere_info, d_quads, d_quad_mat, d_tris, d_pretri, d_meshes, d_xforms, d_mats, d_pairs, d_leaf_table;
+  DBuf d_spheres, d_sphere_info, d_quads, d_quad_mat, d_tris, d_pretri, d_trinorm, d_meshes, d_xforms, d_mats, d_pairs, d_leaf_table;
   DevScene S{};
   int bvh_depth = 0;             // max number of inner nodes on a root-to-leaf path
   bool has_unknown_material = false;
@@ -476,6 +476,7 @@ int prepare_scene(ptmi_ctx* c) {
   }
   HIP_TRY(c, up(c->d_meshes, c->h_meshes.data(), c->h_meshes.size() * 4));
   HIP_TRY(c, c->d_pretri.ensure(std::max<size_t>((size_t)n_tri * 64, 16)));
+  HIP_TRY(c, c->d_trinorm.ensure(std::max<size_t>((size_t)n_tri * 48, 16)));
   if (n_tri > 0) {
     // scratch: [first bad triangle index][mesh material words...]
     HIP_TRY(c, c->d_scratch.ensure(16 + (size_t)n_mesh * 4));
@@ -483,7 +484,7 @@ int prepare_scene(ptmi_ctx* c) {
     HIP_TRY(c, hipMemcpyAsync(c->d_scratch.p, &none, 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync((char*)c->d_scratch.p + 16, mesh_matword.data(), (size_t)n_mesh * 4, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_pretri_digest, dim3((unsigned)((n_tri + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->d_tris.as<float4>(), n_tri, c->d_meshes.as<int4>(), n_mesh,
-                       reinterpret_cast<const int*>((char*)c->d_scratch.p + 16), c->d_pretri.as<float4>(), c->d_scratch.as<uint32_t>());
+                       reinterpret_cast<const int*>((char*)c->d_scratch.p + 16), c->d_pretri.as<float4>(), c->d_trinorm.as<float4>(), c->d_scratch.as<uint32_t>());
     HIP_TRY(c, hipGetLastError());
     uint32_t bad = none;
     HIP_TRY(c, hipMemcpyAsync(&bad, c->d_scratch.p, 4, hipMemcpyDeviceToHost, c->stream));
@@ -507,6 +508,7 @@ int prepare_scene(ptmi_ctx* c) {
   S.quad_unit_n = c->d_quad_unit_n.as<float4>();
   S.tris = c->d_tris.as<float4>();
   S.pretri = c->d_pretri.as<float4>();
+  S.trinorm = c->d_trinorm.as<float4>();
   S.meshes = c->d_meshes.as<int4>();
   S.xforms = c->d_xforms.as<float4>();
   S.mats = c->d_mats.as<float4>();
@@ -1258,7 +1260,7 @@ void ptmi_destroy(ptmi_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   drain_spans(c);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
-  for (DBuf* b : {&c->d_quad_unit_n, &c->d_spheres, &c->d_sphere_info, &c->d_quads, &c->d_quad_mat, &c->d_tris, &c->d_pretri, &c->d_meshes, &c->d_xforms,
+  for (DBuf* b : {&c->d_quad_unit_n, &c->d_spheres, &c->d_sphere_info, &c->d_quads, &c->d_quad_mat, &c->d_tris, &c->d_pretri, &c->d_trinorm, &c->d_meshes, &c->d_xforms,
                   &c->d_mats, &c->d_pairs, &c->d_leaf_table, &c->d_fb_own, &c->d_q0[0], &c->d_q0[1], &c->d_q1[0], &c->d_q1[1], &c->d_q2[0],
                   &c->d_q2[1], &c->d_tp[0], &c->d_tp[1], &c->d_hm[0], &c->d_hm[1], &c->d_uv, &c->d_acc, &c->d_pixsum, &c->d_touched, &c->d_ctl, &c->d_totals,
                   &c->d_scratch, &c->d_spill, &c->d_heads, &c->d_fb_gather, &c->d_fb_stage, &c->d_bvh_rows, &c->d_diag[0], &c->d_diag[1], &c->d_diag[2], &c->d_diag[3]})

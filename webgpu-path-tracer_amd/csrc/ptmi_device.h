@@ -179,6 +179,8 @@ struct DevScene {
   const int2* sphere_info;  // {material word, is_volume}
   const float4* quads;  // 5 float4 / quad
   const int* quad_mat;      // material word per quad
+  const float4* trinorm;      // 3 x float4 per triangle: the vertex normals nA, nB, nC (common.wgsl:230) with the mesh's transform index in nA.w — what
+                              // resolve_hit needs of a triangle hit in one 48-byte run (the raw 96-byte record + the pretri record: three cache lines)
   const float4* quad_unit_n;  // normalize(quad.normal), evaluated once per quad by k_quad_digest with the very same norm3()
   const float4* tris;    // 6 float4 / triangle (raw)
   const float4* pretri;  // 4 float4 / triangle
@@ -809,9 +811,9 @@ DEV TriFetch tri_fetch(const DevScene& S, const float2* __restrict__ uvbuf, uint
   if ((prim >> 28) == K_TRI) {
     const uint32_t idx = prim & 0x0fffffffu;
     f.uv = uvbuf[slot];
-    const float4* tr = S.tris + 6 * (size_t)idx;
-    f.nA = tr[3], f.nB = tr[4], f.nC = tr[5];
-    f.gid = __float_as_int(S.pretri[4 * (size_t)idx + 2].w);  // = meshes[i32(nC.w)].global_id, kept in the traversal digest
+    const float4* tn = S.trinorm + 3 * (size_t)idx;
+    f.nA = tn[0], f.nB = tn[1], f.nC = tn[2];
+    f.gid = __float_as_int(f.nA.w);  // = meshes[i32(nC.w)].global_id, put there by k_pretri_digest
   }
   return f;
 }
@@ -823,9 +825,9 @@ DEV TriFetch tri_fetch_uv(const DevScene& S, float2 uv, uint32_t prim) {
   f.gid = 0;
   if ((prim >> 28) == K_TRI) {
     const uint32_t idx = prim & 0x0fffffffu;
-    const float4* tr = S.tris + 6 * (size_t)idx;
-    f.nA = tr[3], f.nB = tr[4], f.nC = tr[5];
-    f.gid = __float_as_int(S.pretri[4 * (size_t)idx + 2].w);
+    const float4* tn = S.trinorm + 3 * (size_t)idx;
+    f.nA = tn[0], f.nB = tn[1], f.nC = tn[2];
+    f.gid = __float_as_int(f.nA.w);
   }
   return f;
 }

@@ -1250,7 +1250,8 @@ __global__ void k_quad_digest(const float4* __restrict__ quads, int n, float4* _
 // the shader performs per test (common.wgsl:199-201), the same f32 operations in the same order.  A mesh id outside [0, n_meshes)
 // is reported through `first_bad` (smallest offending triangle index) instead of being dereferenced.
 __global__ __launch_bounds__(kBlock) void k_pretri_digest(const float4* __restrict__ tris, int n_tris, const int4* __restrict__ meshes, int n_meshes,
-                                                          const int* __restrict__ mesh_matword, float4* __restrict__ pretri, uint32_t* __restrict__ first_bad) {
+                                                          const int* __restrict__ mesh_matword, float4* __restrict__ pretri, float4* __restrict__ trinorm,
+                                                          uint32_t* __restrict__ first_bad) {
   const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
   if (i >= n_tris) return;
   const float4* t = tris + 6 * (size_t)i;
@@ -1269,6 +1270,11 @@ __global__ __launch_bounds__(kBlock) void k_pretri_digest(const float4* __restri
   o[1] = make_float4(ABx, ABy, ABz, __int_as_float(mesh_matword[mesh]));
   o[2] = make_float4(ACx, ACy, ACz, __int_as_float(me.z));  // the mesh's global_id = its transform index
   o[3] = make_float4(ABy * ACz - ABz * ACy, ABz * ACx - ABx * ACz, ABx * ACy - ABy * ACx, 0.0f);
+  const float4 nA = t[3], nB = t[4], nC = t[5];  // the shading normals of the winning hit (common.wgsl:230), copied bit for bit
+  float4* tn = trinorm + 3 * (size_t)i;
+  tn[0] = make_float4(nA.x, nA.y, nA.z, __int_as_float(me.z));
+  tn[1] = make_float4(nB.x, nB.y, nB.z, 0.0f);
+  tn[2] = make_float4(nC.x, nC.y, nC.z, 0.0f);
 }
 
 // ---- test hooks ------------------------------------------------------------------------------------
