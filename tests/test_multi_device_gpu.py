@@ -10,6 +10,17 @@ from conftest import assert_same_bits, cornell_view
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["wavefront", "mixed"])
+def pipeline(request, monkeypatch):
+    """These images are small enough for k_tail to take every shard's queue whole at step 0 (the library's default): run every case through the
+    per-bounce kernels as well (PTMI_TAIL_LIMIT=0), so that the tile arithmetic of k_generate / k_bvh / k_shade stays under test."""
+    if request.param == "wavefront":
+        monkeypatch.setenv("PTMI_TAIL_LIMIT", "0")
+    else:
+        monkeypatch.delenv("PTMI_TAIL_LIMIT", raising=False)
+    return request.param
+
+
 def _render(pkg, devices, b, view, w, h, frames, **params):
     with pkg.Context(devices) as ctx:
         ctx.upload_scene(b)
