@@ -167,6 +167,7 @@ struct ptmi_ctx {
   uint32_t last_frame = 0;
   float last_view[16];
   int static_streak = 0;  // consecutive ptmi_render_frame calls with the same view, frame numbers +1, no reset
+  bool interactive = false;  // inside ptmi_render_frame: its batches grow 8 -> 64 frames while the user watches — no placement search (40 ms each)
   int ahead_batch = 8;
 
   // Multi-device context (ptmi_create_multi): this object is local device 0, `peers` are the contexts of local devices
@@ -557,13 +558,13 @@ int ensure_paths(ptmi_ctx* c, size_t npaths, int n_ctl, bool need_pixsum) {
     c->slot_cap = slots;
     c->pixsum_alloc = false;
     // Where the driver puts the queue arrays decides how often their streams meet in the same HBM channels: k_shade runs up to 12 % slower
-    // in some contexts than in others, for their whole life (DESIGN.md §4 "placement").  So for batches worth the trouble (>= 4 Mi slots): allocate
+    // in some contexts than in others, for their whole life (DESIGN.md §4 "placement").  So for batches worth the trouble (>= 16 Mi slots — smaller ones belong to k_tail or last microseconds —, not from ptmi_render_frame): allocate
     // up to PTMI_PLACEMENT_TRIES (4) sets, time the step's access pattern on each (k_placement_probe, ~30 ms per set), keep the fastest.  Two sets
     // exist at a time; an extra allocation that fails just ends the search.
     const int tries = getenv("PTMI_PLACEMENT_TRIES") ? atoi(getenv("PTMI_PLACEMENT_TRIES")) : 4;
     // (sets of more than 32 GB are taken as they come: allocating and releasing 76 GB three more times costs seconds, and the long launches of
     // such batches showed no placement effect — configs[2] at 256 spp)
-    if (tries > 1 && slots >= ((size_t)1 << 22) && slots * 120 <= ((size_t)32 << 30)) {
+    if (tries > 1 && !c->interactive && slots >= ((size_t)1 << 24) && slots * 120 <= ((size_t)32 << 30)) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
       HIP_TRY(c, hipEventCreate(&e0));
       HIP_TRY(c, hipEventCreate(&e1));
@@ -886,6 +887,9 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
     if (const uint32_t tail_limit = s == 0 ? tail_limit_first : tail_limit_later) {
       int lr = launch_tail(c, rc, P, ctl + s, s == 0 ? 1 : 0, tail_limit);
       if (lr) return lr;
+      // step 0's queue is the whole batch (k_generate fills one slot per path): if that fits the limit k_tail has just been handed all of it —
+      // nothing is left for the per-bounce kernels, and a lone frame is three launches instead of 3 x MAX_BOUNCES + 2
+      if (s == 0 && total <= tail_limit) break;
     }
     {
       int lr = launch_intersect(c, P, ctl + s, bound, false);
@@ -1529,7 +1533,9 @@ static int render_frame_one(ptmi_ctx* c, const float* u) {
   } else {
     c->ahead_batch = 8;
   }
+  c->interactive = true;
   r = render_batch(c, view, k, batch, reset, 1);
+  c->interactive = false;
   if (r) return r;
   if (batch > 1) {
     A.valid = true;
