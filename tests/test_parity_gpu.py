@@ -590,7 +590,7 @@ def test_auto_batch_shrinks_when_memory_is_short(pkg, oracle, monkeypatch):
 
 
 def test_placement_search_is_invisible(pkg, monkeypatch):
-    """A context that allocates queue arrays for >= 4 Mi slots tries up to PTMI_PLACEMENT_TRIES sets and keeps the one the memory system
+    """A context that allocates queue arrays for >= 16 Mi slots tries up to PTMI_PLACEMENT_TRIES sets and keeps the one the memory system
     serves fastest (ptmi.hip, ensure_paths): whichever set it ends up with, the image and the counters are the same."""
     b = pkg.scenes.golden_buffers("c2")
     view = cornell_view(pkg)
@@ -599,9 +599,9 @@ def test_placement_search_is_invisible(pkg, monkeypatch):
         monkeypatch.setenv("PTMI_PLACEMENT_TRIES", tries)
         with pkg.Context(0) as ctx:
             ctx.upload_scene(b)
-            ctx.set_params(max_bounces=4, frames_in_flight=4)
+            ctx.set_params(max_bounces=4, frames_in_flight=8)
             ctx.resize(1920, 1080)
-            ctx.render(view, 1, 4)  # 8.3 M paths: 9.4 M slots per queue array
+            ctx.render(view, 1, 8)  # 16.6 M paths: 20.8 M slots per queue array
             results.append((ctx.read_framebuffer(), ctx.stats()["rays"]))
     assert_same_bits(results[0][0], results[1][0], "placement search off / on")
     assert results[0][1] == results[1][1]
