@@ -57,8 +57,10 @@ def test_bench_line_contract_with_its_own_pmc_passes():
     if "pmc_note" not in roof:  # rocprofv3 is on the GPU box: the passes must have produced the fractions
         assert roof["bound"] in ("valu_issue", "hbm", "l1_gather") and 0 < roof["frac"] <= 1 and roof["achieved"] <= roof["peak"] * (1 + 1e-9)
         assert roof["traffic"] > 0 and "rocprofv3 --pmc passes made by this run" in roof["pmc_source"]
+        assert "valu_busy_frac" in tab[roof["kernel"]]
         for v in tab.values():
-            assert 0 <= v["valu_busy_frac"] <= 1 and 0 <= v["hbm_frac"] <= 1 and 0 < v["active_lane_frac"] <= 1
+            if "valu_busy_frac" in v:  # (a batch this small is k_generate + k_tail + k_accumulate: the per-bounce kernels are never launched)
+                assert 0 <= v["valu_busy_frac"] <= 1 and 0 <= v["hbm_frac"] <= 1 and 0 < v["active_lane_frac"] <= 1
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["single_thread"]["cores"] == 1 and cb["single_thread"]["value"] > 0
 
