@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PTMI_API_VERSION 3
+#define PTMI_API_VERSION 4
 
 typedef struct ptmi_ctx ptmi_ctx;
 
@@ -101,6 +101,13 @@ typedef struct ptmi_stats {
   double tail_ms;        /* sum over k_tail launches: short queues traced to the end in one launch (most decline
                           * at once); counts towards neither intersect_ms nor shade_ms       */
   uint64_t tail_launches;
+  /* API v4 */
+  uint64_t reduce_mode;  /* how this context sums its devices' accumulation buffers (ptmi_create_multi): 0 = single device, nothing to sum;
+                          * 1 = ncclReduce (RCCL over xGMI); 2 = peer copies + add kernel (shards share a GPU, or PTMI_MULTI_REDUCE=copy);
+                          * 3 = peer copies + add kernel as a FALLBACK after librccl failed to load / initialise / reduce (ptmi_reduce_info says why) */
+  uint64_t peer_links;   /* directed root<->peer device pairs with hipDeviceEnablePeerAccess in force */
+  uint64_t placement_sets; /* queue-array sets the last placement search timed (0 = none ran; ensure_paths) */
+  double placement_ms;   /* host time that search added to the render that allocated the path buffers */
 } ptmi_stats;
 
 /* One hitScene result, the fields of the reference's HitRecord (shaders/header.wgsl:119-125). */
@@ -129,11 +136,20 @@ int ptmi_create(ptmi_ctx** out, int device_id);
  * (renderer.js:91-124,184-191) needs no change.  A device id may be listed more than once (its shards then share that
  * GPU and are summed by a kernel instead: how the multi-device path is tested on a one-GPU box). */
 int ptmi_create_multi(ptmi_ctx** out, const int* device_ids, int n_devices);
+/* Number of HIP devices this process sees (0 if the runtime reports none or fails). */
+int ptmi_device_count(void);
+/* One line about the multi-device reduce of this context: "ncclReduce over 8 devices (RCCL, xGMI)", "add kernel (shards share a GPU)", or
+ * "FALLBACK: hipMemcpyPeer + add (<what failed>)" when librccl could not be loaded, ncclCommInitAll failed or a reduce failed — the context
+ * then keeps working through peer copies (same bits) instead of failing.  Owned by the context. */
+const char* ptmi_reduce_info(const ptmi_ctx* ctx);
 void ptmi_destroy(ptmi_ctx* ctx);
 
 void ptmi_default_params(ptmi_params* p);
 int ptmi_set_params(ptmi_ctx* ctx, const ptmi_params* p);
 int ptmi_get_params(const ptmi_ctx* ctx, ptmi_params* p);
+/* The PTMI_* tuning variables (kernel grid sizes, k_tail's hand-over limit, render-ahead, ...) are read from the environment ONCE, by
+ * ptmi_create; this reads them again for a live context (tests and A/B scripts).  The render path never calls getenv. */
+int ptmi_reload_tuning(ptmi_ctx* ctx);
 
 /* replaces createStorageBuffer_WriteOnly(label, typedArray) (webgpu-utils.js:29-41, renderer.js:93-99):
  * copies `bytes` bytes (a multiple of the buffer's stride; 0 allowed = empty array). */
@@ -212,7 +228,9 @@ int ptmi_selftest(ptmi_ctx* ctx, int which, uint64_t* mismatches, uint32_t* firs
  * them, the median-split build, and the reordering of the triangles into leaf order (lib/scene.js:257) — all on the GPU, nothing comes back:
  * the BVH rows (byte-identical to ptmi_build_bvh's and the reference's) stay in device memory as binding 9 and the traversal digests are
  * made from them there.  871 k triangles: ~15 ms (the reference's JavaScript: seconds; benchmarks.txt:19).  A later ptmi_upload(PTMI_BUF_BVH)
- * replaces the tree; uploading other triangles requires building again. */
+ * replaces the tree; after an upload of triangles, meshes or transforms the tree is stale and every render fails with PTMI_ERR_BAD_SCENE
+ * until it is built again (or a BVH is uploaded).  At most 2^23 triangles: node ids are f32 in the rows (exact below 2^24), as in the
+ * reference's own format — more returns PTMI_ERR_UNSUPPORTED. */
 int ptmi_build_scene_bvh(ptmi_ctx* ctx);
 /* Test / tool hook: copies the context's triangles (which = 5: in their current order) or BVH rows (which = 9) to the host; bytes must be
  * exactly the buffer's size (triangles x 96, (2 x triangles - 1) x 48 for a tree from ptmi_build_scene_bvh). */

@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert sorted(pkg.ptmi.SYMBOLS) == declared
     for name in declared:
         assert hasattr(L, name), name
-    assert L.ptmi_version() == 3
+    assert L.ptmi_version() == 4
 
 
 def test_status_strings_and_defaults(pkg):
@@ -32,7 +32,7 @@ def test_status_strings_and_defaults(pkg):
 
 def test_struct_sizes_match_header(pkg):
     assert ctypes.sizeof(pkg.Params) == 4 * 5 + 12 + 4 + 4 + 20
-    assert ctypes.sizeof(pkg.ptmi.Stats) == 12 * 8 + 8 * 8 + 3 * 8 + 2 * 8  # (+ tail_ms, tail_launches: k_tail)
+    assert ctypes.sizeof(pkg.ptmi.Stats) == 12 * 8 + 8 * 8 + 3 * 8 + 2 * 8 + 4 * 8  # (+ tail_ms, tail_launches: k_tail; API v4: reduce_mode, peer_links, placement_*)
     assert pkg.ptmi.HIT_DTYPE.itemsize == 4 + 4 + 12 + 12 + 4 + 64
 
 

@@ -12,16 +12,18 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True, params=["wavefront", "mixed", "tail"])
-def pipeline(request, monkeypatch):
+def pipeline(request, monkeypatch, ctx):
     """Every case three times: through the wavefront kernels alone (k_generate, k_bvh, k_shade per bounce), with the library's default
     hand-over (k_tail traces a queue to the end once it is at most 2 Mi slots long at step 0, 512 Ki later: the small cases never leave
-    k_tail, the full-size ones switch in mid-batch), and with k_tail taking every queue whole from step 0.  PTMI_TAIL_LIMIT is read per render."""
+    k_tail, the full-size ones switch in mid-batch), and with k_tail taking every queue whole from step 0.  The library reads PTMI_TAIL_LIMIT
+    when a context is created (contexts the tests make themselves) and in ptmi_reload_tuning (the session's context)."""
     if request.param == "wavefront":
         monkeypatch.setenv("PTMI_TAIL_LIMIT", "0")
     elif request.param == "tail":
         monkeypatch.setenv("PTMI_TAIL_LIMIT", str(1 << 30))
     else:
         monkeypatch.delenv("PTMI_TAIL_LIMIT", raising=False)
+    ctx.reload_tuning()
     return request.param
 
 
@@ -663,6 +665,17 @@ def test_scene_bvh_built_on_the_device_is_the_host_pipeline_bit_for_bit(ctx, pkg
         assert_same_bits(got, want, name + " rendered from the device-resident tree")
         for k in ("rays", "node_visits", "tri_tests", "quad_tests", "mat_fetches"):
             assert st[k] == ost[k], (name, k)
+    # the tree describes the triangles, meshes and transforms it was built over: uploading any of them again — the SAME number of triangles
+    # included (mesh order under a tree over leaf order would trace silently wrong) — is refused until the tree is built again
+    for which, arr in (("triangles", raw["triangles"]), ("transforms", raw["transforms"]), ("meshes", raw["meshes"])):
+        ctx.upload(which, np.asarray(arr, np.int32 if which == "meshes" else np.float32))
+        with pytest.raises(pkg.PtmiError, match="build again"):
+            ctx.render(view, 1, 1)
+        ctx.upload("triangles", np.asarray(raw["triangles"], np.float32))  # (a build reorders what is there: start from mesh order again)
+        ctx.build_scene_bvh()
+        ctx.clear()
+        ctx.render(view, 1, 2)
+        assert_same_bits(ctx.read_framebuffer(), want, "rebuilt after uploading the %s again" % which)
     # a different number of triangles under a device-resident tree is refused; an uploaded BVH takes over again
     ctx.upload("triangles", np.asarray(host["triangles"], np.float32)[: 24 * 100])
     with pytest.raises(pkg.PtmiError):
@@ -670,6 +683,16 @@ def test_scene_bvh_built_on_the_device_is_the_host_pipeline_bit_for_bit(ctx, pkg
     ctx.upload_scene(pkg.scenes.golden_buffers("c2"))
     ctx.set_params(max_bounces=4)
     ctx.render(view, 1, 1)
+
+
+def test_scene_bvh_on_the_device_refuses_more_triangles_than_f32_node_ids_can_name(ctx, pkg):
+    """Node and primitive ids are f32 in the BVH rows (lib/BVH/bvhBuilder.js:45,49): 2n - 1 nodes are exact only below 2^24, so the device
+    builder takes at most 2^23 triangles (above that the pair records could hold wrong child links)."""
+    n = (1 << 23) + 1
+    ctx.upload_scene(pkg.scenes.golden_buffers("c2"))
+    ctx.upload("triangles", np.zeros(n * 24, np.float32))
+    with pytest.raises(pkg.PtmiError, match="2\\^23"):
+        ctx.build_scene_bvh()
 
 
 def _two_mesh_scene(pkg):

@@ -1,4 +1,4 @@
-"""k_bvh time vs waves per CU on a mid-size mesh whose stacks leave room in LDS (tuning aid; PTMI_WAVES_PER_CU is read per launch)."""
+"""k_bvh time vs waves per CU on a mid-size mesh whose stacks leave room in LDS (tuning aid; PTMI_WAVES_PER_CU is read by ptmi_reload_tuning)."""
 import os, sys, time
 sys.path.insert(0, '.')
 import __graft_entry__ as g
@@ -13,6 +13,7 @@ stack = int(sys.argv[3]) if len(sys.argv) > 3 else 24
 ctx.set_params(max_bounces=8, stack_size=stack); ctx.resize(1920, 1080)
 for w in (8, 12, 16, 20, 24):
     os.environ["PTMI_WAVES_PER_CU"] = str(w)
+    ctx.reload_tuning()
     ctx.clear(); ctx.render(view, 1, 16); ctx.synchronize(); ctx.reset_stats(); ctx.set_timing(1)
     ctx.clear(); ctx.render(view, 1, 32); ctx.synchronize(); st = ctx.stats(); ctx.set_timing(0)
     print("tris %d waves/CU %d: bvh %.1f ms, shade %.1f ms, %.0f Mrays/s" % (n, w, st["bvh_ms"], st["shade_ms"], st["rays"] / (st["render_ms"] / 1e3) / 1e6), flush=True)

@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>  // types and prototypes only: librccl is loaded on first multi-device use (see Rccl below)
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -25,7 +26,9 @@ using namespace ptmi;
 int ptmi_bvhdev_build_scene(void* stream, const float* d_tris, uint32_t n, const int32_t* h_meshes, int n_meshes, const float* h_xforms, int n_xforms, float* d_rows,
                             float* d_tris_out, int* depth_out, uint32_t* bad_tri);
 int ptmi_bvhdev_make_pairs(void* stream, const float* d_rows, uint32_t nn, float* d_pairs);
+#ifdef PTMI_EXPERIMENTS
 int ptmi_diag_sort_pairs(void* stream, uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, uint32_t n);
+#endif
 
 namespace {
 
@@ -113,11 +116,34 @@ struct PeerWorker {
   }
 };
 
+// Tuning knobs (PTMI_* environment variables): read ONCE, when the context is created (ptmi_reload_tuning reads them again — tests and A/B
+// scripts that change a variable under a live context call it); the render path itself never touches the environment.
+struct Tuning {
+  int lds_stack = 10;          // PTMI_LDS_STACK: traversal stack entries per lane kept in LDS (deeper ones: per-wave global spill area)
+  bool noabort = true;         // PTMI_NOABORT=0: keep the literal stack discipline even where Q7's abort cannot trigger
+  int waves_per_cu = 0;        // PTMI_WAVES_PER_CU: k_bvh's grid (0 = auto)
+  int bvh_teams = 16;          // PTMI_BVH_TEAMS: claim counters of k_bvh
+  int refill = kRefillThreshold, leaf_batch = kLeafBatch, bvh_range = (int)kBvhRange;  // PTMI_REFILL, PTMI_LEAF_BATCH, PTMI_BVH_RANGE
+  int tail_waves_per_cu = 16;  // PTMI_TAIL_WAVES_PER_CU
+  int sort = -1;               // PTMI_SORT: k_shade sorts its chunks by material class (-1 = when the scene has more than one)
+  int shade_blocks_per_cu = 0; // PTMI_SHADE_BLOCKS_PER_CU (0 = from the variant's occupancy)
+  int tail_limit = -1;         // PTMI_TAIL_LIMIT: k_tail takes queues of at most this many slots (-1 = kTailLimitFirst / kTailLimitLater, 0 = never)
+  bool render_ahead = true;    // PTMI_RENDER_AHEAD=0
+  int path_budget_log2 = 29;   // PTMI_PATH_BUDGET_LOG2: paths per wavefront pass with frames_in_flight = auto
+  int placement_tries = 4;     // PTMI_PLACEMENT_TRIES
+  bool debug_placement = false;
+#ifdef PTMI_EXPERIMENTS
+  int bvh_kernel = 3;          // PTMI_BVH_KERNEL: 1 = first edition, 2 = second edition with one unified fetch, 3 = the shipped one
+  int diag_sort = 0;           // PTMI_DIAG_SORT
+#endif
+};
+
 struct ptmi_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
   ptmi_params prm;
+  Tuning tun;
   int num_cus = 256;
 
   // host copies of the uploaded arrays (reference layouts)
@@ -131,6 +157,7 @@ struct ptmi_ctx {
   DBuf d_bvh_rows;
   bool bvh_on_device = false;
   size_t bvh_dev_prims = 0;  // triangles the device-resident tree was built over
+  bool bvh_dev_stale = false;  // triangles / meshes / transforms were uploaded after the build: its boxes and leaf order describe another scene
   int bvh_dev_depth = 0;
   DBuf d_spheres, d_sphere_info, d_quads, d_quad_mat, d_tris, d_pretri, d_trinorm, d_meshes, d_xforms, d_mats, d_pairs, d_leaf_table;
   DevScene S{};
@@ -150,7 +177,9 @@ struct ptmi_ctx {
   size_t slot_cap = 0;  // slots per queue buffer (paths + room for the holes k_shade's regions leave)
   DBuf d_q0[2], d_q1[2], d_q2[2], d_tp[2], d_hm[2];  // slot-indexed live state and hit records, ping-pong
   DBuf d_uv, d_acc, d_pixsum, d_touched, d_ctl, d_totals, d_scratch, d_spill, d_heads;
+#ifdef PTMI_EXPERIMENTS
   DBuf d_diag[4];  // PTMI_DIAG_SORT: keys / slots, in / out
+#endif
   int ctl_cap = 0;
 
   // Render-ahead of ptmi_render_frame (see there): per-frame colours of frames [frame0, frame0 + count) sit in d_acc,
@@ -173,11 +202,15 @@ struct ptmi_ctx {
   // Multi-device context (ptmi_create_multi): this object is local device 0, `peers` are the contexts of local devices
   // 1..n-1 (plain single-device contexts).  The caller's shard (ptmi_set_shard) is subdivided among the n of them.
   bool multi = false;
+  bool shares_device = false;  // another shard of the same multi-device context lives on this GPU
   std::vector<ptmi_ctx*> peers;
   PeerWorker* worker = nullptr;  // a peer's host thread (created on first use)
   int proc_rank = 0, proc_world = 1, proc_tile = 4096;
   bool use_rccl = false;
   std::vector<ncclComm_t> comms;  // one per local device, same order as {this, peers...}
+  int reduce_mode = 0;            // ptmi_stats.reduce_mode: how the multi-device sum runs (0 single device, 1 RCCL, 2 peer copies + add, 3 the same as a FALLBACK)
+  int peer_links = 0;             // directed device pairs (root <-> peer) with peer access enabled
+  std::string reduce_info;        // ptmi_reduce_info
   DBuf d_fb_gather, d_fb_stage;   // on this device: the sum of all local accumulation buffers / a peer's buffer in transit
 
   bool batch_enqueued = false;  // render_batch: has anything been put on the stream yet? (a failure before that point may be retried)
@@ -351,6 +384,8 @@ int prepare_scene(ptmi_ctx* c) {
       snprintf(msg, sizeof msg, "the device-resident BVH was built over %zu triangles, %d are uploaded now (build again, or upload a BVH)", c->bvh_dev_prims, n_tri);
       return fail(c, PTMI_ERR_BAD_SCENE, msg);
     }
+    if (c->bvh_dev_stale)  // same count, other content: the tree's world-space boxes and leaf order belong to what was there before
+      return fail(c, PTMI_ERR_BAD_SCENE, "triangles, meshes or transforms were uploaded after ptmi_build_scene_bvh: the device-resident BVH describes the earlier scene (build again, or upload a BVH)");
     c->bvh_depth = c->bvh_dev_depth;
     const size_t n_inner = (size_t)(n_node - 1) / 2;
     HIP_TRY(c, c->d_pairs.ensure(std::max<size_t>(n_inner * 64, 16)));
@@ -561,13 +596,26 @@ int ensure_paths(ptmi_ctx* c, size_t npaths, int n_ctl, bool need_pixsum) {
     // in some contexts than in others, for their whole life (DESIGN.md §4 "placement").  So for batches worth the trouble (>= 16 Mi slots — smaller ones belong to k_tail or last microseconds —, not from ptmi_render_frame): allocate
     // up to PTMI_PLACEMENT_TRIES (4) sets, time the step's access pattern on each (k_placement_probe, ~30 ms per set), keep the fastest.  Two sets
     // exist at a time; an extra allocation that fails just ends the search.
-    const int tries = getenv("PTMI_PLACEMENT_TRIES") ? atoi(getenv("PTMI_PLACEMENT_TRIES")) : 4;
+    const int tries = c->tun.placement_tries;
     // (sets of more than 32 GB are taken as they come: allocating and releasing 76 GB three more times costs seconds, and the long launches of
     // such batches showed no placement effect — configs[2] at 256 spp)
-    if (tries > 1 && !c->interactive && slots >= ((size_t)1 << 24) && slots * 120 <= ((size_t)32 << 30)) {
-      hipEvent_t e0 = nullptr, e1 = nullptr;
-      HIP_TRY(c, hipEventCreate(&e0));
-      HIP_TRY(c, hipEventCreate(&e1));
+    c->stats.placement_sets = 0;
+    c->stats.placement_ms = 0.0;
+    // (not when shards of this context share the GPU — their probes would time each other —, nor when the board could not hold a second set)
+    size_t mem_free = 0, mem_total = 0;
+    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = 0, (void)hipGetLastError();
+    if (tries > 1 && !c->interactive && !c->shares_device && slots >= ((size_t)1 << 24) && slots * 120 <= ((size_t)32 << 30) && mem_free >= slots * 120 * 2) {
+      const auto t_search = std::chrono::steady_clock::now();
+      struct Events {  // destroyed on every way out of the search
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Events() {
+          if (e0) (void)hipEventDestroy(e0);
+          if (e1) (void)hipEventDestroy(e1);
+        }
+      } ev;
+      HIP_TRY(c, hipEventCreate(&ev.e0));
+      HIP_TRY(c, hipEventCreate(&ev.e1));
+      const hipEvent_t e0 = ev.e0, e1 = ev.e1;
       const uint32_t pn = (uint32_t)std::min<size_t>(slots, (size_t)1 << 26);
       auto score = [&](float* ms) -> hipError_t {
         float total = 0.0f;
@@ -588,7 +636,8 @@ int ensure_paths(ptmi_ctx* c, size_t npaths, int n_ctl, bool need_pixsum) {
       };
       float best = 0.0f;
       HIP_TRY(c, score(&best));
-      if (getenv("PTMI_DEBUG_PLACEMENT")) fprintf(stderr, "ptmi placement: set 0 %.3f ms\n", best);
+      c->stats.placement_sets = 1;
+      if (c->tun.debug_placement) fprintf(stderr, "ptmi placement: set 0 %.3f ms\n", best);
       DBuf* mine[10] = {&c->d_q0[0], &c->d_q0[1], &c->d_q1[0], &c->d_q1[1], &c->d_q2[0], &c->d_q2[1], &c->d_tp[0], &c->d_tp[1], &c->d_hm[0], &c->d_hm[1]};
       const size_t width[10] = {16, 16, 16, 16, 16, 16, 8, 8, 4, 4};
       for (int t = 1; t < tries; t++) {
@@ -599,7 +648,8 @@ int ensure_paths(ptmi_ctx* c, size_t npaths, int n_ctl, bool need_pixsum) {
         if (ok) {
           for (int k = 0; k < 10; k++) std::swap(*mine[k], cand[k]);  // (cand now holds the best set so far)
           ok = score(&ms) == hipSuccess;
-          if (getenv("PTMI_DEBUG_PLACEMENT")) fprintf(stderr, "ptmi placement: set %d %.3f ms\n", t, ms);
+          if (ok) c->stats.placement_sets++;
+          if (c->tun.debug_placement) fprintf(stderr, "ptmi placement: set %d %.3f ms\n", t, ms);
           if (!ok || ms >= best) {
             for (int k = 0; k < 10; k++) std::swap(*mine[k], cand[k]);  // keep the old one
           } else {
@@ -609,8 +659,7 @@ int ensure_paths(ptmi_ctx* c, size_t npaths, int n_ctl, bool need_pixsum) {
         for (int k = 0; k < 10; k++) cand[k].release();
         if (!ok) break;
       }
-      (void)hipEventDestroy(e0);
-      (void)hipEventDestroy(e1);
+      c->stats.placement_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_search).count();
     }
   }
   if (need_pixsum && !c->pixsum_alloc) {
@@ -653,8 +702,8 @@ const void* shade_kernel(bool is, bool so, bool cn, bool mu) {
   }
 #define PTMI_SK(I, S, C, M) \
   if (is == I && so == S && cn == C && mu == M) return reinterpret_cast<const void*>(&k_shade<I, S, C, M>)
-  PTMI_SK(false, false, false, false); PTMI_SK(false, false, false, true); PTMI_SK(false, false, true, false); PTMI_SK(false, false, true, true);
-  PTMI_SK(false, true, false, false); PTMI_SK(false, true, false, true); PTMI_SK(false, true, true, false); PTMI_SK(false, true, true, true);
+  PTMI_SK(false, false, false, true); PTMI_SK(false, false, true, true);  // (IS = MULTI = false is k_shade6 above: those four are never instantiated)
+  PTMI_SK(false, true, false, true); PTMI_SK(false, true, true, true);
   PTMI_SK(true, false, false, false); PTMI_SK(true, false, false, true); PTMI_SK(true, false, true, false); PTMI_SK(true, false, true, true);
   PTMI_SK(true, true, false, false); PTMI_SK(true, true, false, true); PTMI_SK(true, true, true, false); PTMI_SK(true, true, true, true);
 #undef PTMI_SK
@@ -666,6 +715,29 @@ int stack_alloc_for(const ptmi_ctx* c) { return std::max(1, std::min(c->prm.stac
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
+}
+void load_tuning(ptmi_ctx* c) {
+  Tuning t;
+  t.lds_stack = std::max(1, env_int("PTMI_LDS_STACK", t.lds_stack));
+  t.noabort = env_int("PTMI_NOABORT", 1) != 0;
+  t.waves_per_cu = env_int("PTMI_WAVES_PER_CU", 0);
+  t.bvh_teams = (int)std::max<uint32_t>(1, std::min<uint32_t>(kMaxTeams, (uint32_t)env_int("PTMI_BVH_TEAMS", t.bvh_teams)));
+  t.refill = env_int("PTMI_REFILL", t.refill);
+  t.leaf_batch = env_int("PTMI_LEAF_BATCH", t.leaf_batch);
+  t.bvh_range = std::max(64, std::min(1 << 16, env_int("PTMI_BVH_RANGE", t.bvh_range))) & ~63;
+  t.tail_waves_per_cu = std::max(1, std::min(32, env_int("PTMI_TAIL_WAVES_PER_CU", t.tail_waves_per_cu)));
+  t.sort = env_int("PTMI_SORT", -1);
+  t.shade_blocks_per_cu = env_int("PTMI_SHADE_BLOCKS_PER_CU", 0);
+  t.tail_limit = env_int("PTMI_TAIL_LIMIT", -1);
+  t.render_ahead = env_int("PTMI_RENDER_AHEAD", 1) != 0;
+  t.path_budget_log2 = std::max(16, std::min(31, env_int("PTMI_PATH_BUDGET_LOG2", t.path_budget_log2)));
+  t.placement_tries = env_int("PTMI_PLACEMENT_TRIES", t.placement_tries);
+  t.debug_placement = getenv("PTMI_DEBUG_PLACEMENT") != nullptr;
+#ifdef PTMI_EXPERIMENTS
+  t.bvh_kernel = env_int("PTMI_BVH_KERNEL", 3);
+  t.diag_sort = env_int("PTMI_DIAG_SORT", 0);
+#endif
+  c->tun = t;
 }
 
 // hitScene, part 2 for the step's queue (k_bvh).  Part 1 has already been run by whoever created the rays (k_generate,
@@ -679,11 +751,12 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
     else hipLaunchKernelGGL(k_prims<false>, dim3(pgrid), dim3(kBlock), 0, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), tot);
   }
   if (c->S.n_nodes <= 0) return PTMI_OK;
+#ifdef PTMI_EXPERIMENTS
   // PTMI_DIAG_SORT=1|2|3 (an experiment, never the product path): hand k_bvh the queue's rays fully sorted by direction octant and origin cell, to
   // measure what ANY ordering of the queue could buy the traversal (the sort itself runs outside the kernel's timing span and is not counted).
   const uint32_t* diag_order = nullptr;
   const uint32_t* diag_keys = nullptr;
-  const int diag = env_int("PTMI_DIAG_SORT", 0);
+  const int diag = c->tun.diag_sort;
   if (diag > 0 && !with_prims) {
     for (int k = 0; k < 4; k++) HIP_TRY(c, c->d_diag[k].ensure((size_t)max_items * 4));
     hipLaunchKernelGGL(k_diag_sort_keys, dim3(pgrid), dim3(kBlock), 0, c->stream, P, ctl, diag, c->d_diag[0].as<uint32_t>(), c->d_diag[2].as<uint32_t>(), max_items);
@@ -698,34 +771,39 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
       diag_order = c->d_diag[3].as<uint32_t>();
     }
   }
+#endif
   ScopedSpan sp(c, T_BVH);
-  // Stack entries per lane: the first kLdsStackEntries in LDS, the rest (rarely reached) in a per-wave spill area.
-  // 10 entries x 512 B + the candidate buffer = 5.5 KB per wave: 28 waves fit a CU's 160 KB, and the second-edition kernel's 66 VGPRs
+  // Stack entries per lane: the first tun.lds_stack (10) in LDS, the rest (rarely reached) in a per-wave spill area.
+  // 10 entries x 512 B + the candidate buffer = 5.5 KB per wave: 28 waves fit a CU's 160 KB, and the kernel's 66 VGPRs
   // admit 7 waves per SIMD.  (Round 3: the kernel runs at the rate of the CU's L1 gather path — tools/gather_probe*.hip, 2.8 clocks per
   // 64-byte record — so occupancy beyond ~18 waves buys 0-3 %: configs[1] 4.53 -> 4.18 ms, configs[3] 482 -> 481.)
-  constexpr int kLdsStackEntries = 10;
+  const Tuning& tun = c->tun;
   const int sa = stack_alloc_for(c);
-  const int le = std::min(sa, std::max(1, env_int("PTMI_LDS_STACK", kLdsStackEntries)));
+  const int le = std::min(sa, tun.lds_stack);
   const int se = sa - le;
   const size_t lds = (size_t)le * 2 * 64 * sizeof(int) + 128 * sizeof(uint32_t);  // stacks (2 words/entry) + candidate buffer
   // The abort of Q7 (hitRay.wgsl:106-109) needs sp to reach STACK_SIZE; sp never exceeds the number of inner nodes on a
   // root-to-leaf path.  PTMI_NOABORT=0 keeps the literal stack discipline for A/B runs.
-  const bool noabort = c->bvh_depth < c->prm.stack_size && env_int("PTMI_NOABORT", 1) != 0;
-  const int edition = env_int("PTMI_BVH_KERNEL", 3);
+  const bool noabort = c->bvh_depth < c->prm.stack_size && tun.noabort;
+#ifdef PTMI_EXPERIMENTS
+  const int edition = tun.bvh_kernel;
+#else
+  constexpr int edition = 3;
+#endif
   int waves_per_cu = (int)std::min<size_t>(edition == 3 ? 28 : 20, (size_t)(160 * 1024) / (lds + 64));  // (editions 1 and 2 need 68-84 VGPRs)
-  if (env_int("PTMI_WAVES_PER_CU", 0) > 0) waves_per_cu = env_int("PTMI_WAVES_PER_CU", 0);  // tuning aid; 0/unset = auto
+  if (tun.waves_per_cu > 0) waves_per_cu = tun.waves_per_cu;  // tuning aid; 0/unset = auto
   const uint32_t want = (max_items + 63) / 64;
   const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(want, (uint32_t)c->num_cus * (uint32_t)waves_per_cu));
   // Range claims go through 16 team counters (128 B apart) instead of one: a launch makes tens of thousands of claims and
   // same-address global atomics serialise at ~11 ns each (configs[1]: +2 %).
-  const uint32_t n_teams = std::max<uint32_t>(1, std::min<uint32_t>(kMaxTeams, (uint32_t)env_int("PTMI_BVH_TEAMS", 16)));
+  const uint32_t n_teams = (uint32_t)tun.bvh_teams;
   // (the counters are zeroed by the kernel that filled this queue)
   HIP_TRY(c, c->d_spill.ensure(std::max<size_t>(16, (size_t)std::max<uint32_t>(grid, (uint32_t)c->num_cus * 32) * (size_t)se * 64 * sizeof(int2))));
-  const int thr = env_int("PTMI_REFILL", kRefillThreshold);
-  const int leaf_batch = env_int("PTMI_LEAF_BATCH", kLeafBatch);
+  const int thr = tun.refill, leaf_batch = tun.leaf_batch;
+  const uint32_t range_cap = (uint32_t)tun.bvh_range;
+#ifdef PTMI_EXPERIMENTS
   // PTMI_BVH_KERNEL: 1 = the first edition of the traversal kernel (rounds 1/2), 2 = second edition with one unified fetch per iteration,
-  // 3 (default) = second edition's state machine in the first edition's two-phase loop — for A/B runs
-  const uint32_t range_cap = (uint32_t)std::max(64, std::min(1 << 16, env_int("PTMI_BVH_RANGE", (int)kBvhRange))) & ~63u;
+  // 3 (default) = the shipped kernel — for A/B runs
 #define PTMI_LAUNCH_BVH_K1(KERNEL)                                                                                                                                    \
   hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), n_teams, c->prm.stack_size, le, se, c->d_spill.as<int2>(), thr, \
                      leaf_batch, tot)
@@ -738,6 +816,11 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
     else if (edition == 2) PTMI_LAUNCH_BVH_K((k_bvh2<CNT, NA, true>)); \
     else PTMI_LAUNCH_BVH_K((k_bvh2<CNT, NA, false>));                  \
   } while (0)
+#else
+#define PTMI_LAUNCH_BVH(CNT, NA)                                                                                                                                       \
+  hipLaunchKernelGGL((k_bvh2<CNT, NA, false>), dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), n_teams, c->prm.stack_size, le, se, \
+                     c->d_spill.as<int2>(), thr, leaf_batch, tot, range_cap)
+#endif
   if (c->counters) {
     if (noabort) PTMI_LAUNCH_BVH(true, true);
     else PTMI_LAUNCH_BVH(true, false);
@@ -746,8 +829,10 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
     else PTMI_LAUNCH_BVH(false, false);
   }
 #undef PTMI_LAUNCH_BVH
+#ifdef PTMI_EXPERIMENTS
 #undef PTMI_LAUNCH_BVH_K
 #undef PTMI_LAUNCH_BVH_K1
+#endif
   HIP_TRY(c, hipGetLastError());
   return PTMI_OK;
 }
@@ -755,11 +840,11 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
 // k_tail in front of a step: traces the step's queue to the end if it is short (PTMI_TAIL_LIMIT slots, 0 = never launched), else returns at once.
 int launch_tail(ptmi_ctx* c, const RenderConst& rc, const Paths& P, StepCtl* ctl, int first, uint32_t limit) {
   const int sa = stack_alloc_for(c);
-  const int le = std::min(sa, std::max(1, env_int("PTMI_LDS_STACK", 10)));
+  const int le = std::min(sa, c->tun.lds_stack);
   const int se = sa - le;
   const size_t lds = (size_t)le * 2 * 64 * sizeof(int);
-  const bool noabort = c->bvh_depth < c->prm.stack_size && env_int("PTMI_NOABORT", 1) != 0;
-  const int waves_per_cu = std::max(1, std::min(32, env_int("PTMI_TAIL_WAVES_PER_CU", 16)));
+  const bool noabort = c->bvh_depth < c->prm.stack_size && c->tun.noabort;
+  const int waves_per_cu = c->tun.tail_waves_per_cu;
   const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>((limit + 63) / 64, (uint32_t)c->num_cus * (uint32_t)waves_per_cu));
   HIP_TRY(c, c->d_spill.ensure(std::max<size_t>(16, (size_t)c->num_cus * 32 * (size_t)se * 64 * sizeof(int2))));  // (k_bvh's grids are no larger: one size for both)
   unsigned long long* tot = c->d_totals.as<unsigned long long>();
@@ -789,6 +874,13 @@ int launch_tail(ptmi_ctx* c, const RenderConst& rc, const Paths& P, StepCtl* ctl
   HIP_TRY(c, hipGetLastError());
   c->stats.tail_launches++;
   return PTMI_OK;
+}
+
+// progressive mode without importance sampling is k_shade6 (80 VGPRs); the k_shade instances for it are never made
+template <bool IS, bool SO, bool CN, bool MU>
+void launch_shade(ptmi_ctx* c, uint32_t sgrid, const RenderConst& rc, const Paths& P, StepCtl* ctl, unsigned long long* tot, int first) {
+  if constexpr (!IS && !MU) hipLaunchKernelGGL((k_shade6<SO, CN>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl, c->d_heads.as<uint32_t>(), tot, first);
+  else hipLaunchKernelGGL((k_shade<IS, SO, CN, MU>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl, c->d_heads.as<uint32_t>(), tot, first);
 }
 
 // `fold` = how many of the batch's leading frames are added to the framebuffer now (-1 = all of them)
@@ -838,13 +930,13 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   const uint32_t bound = total + total / 8 + (uint32_t)c->num_cus * 8 * 1024;  // slots a step's queue can span
   const uint32_t ew_grid = std::max<uint32_t>(1, std::min<uint32_t>((total + kBlock - 1) / kBlock, (uint32_t)c->num_cus * 16));
   // k_shade sorts its chunks by material class only when the scene has more than one (PTMI_SORT=0/1 overrides, for A/B runs)
-  const int sort_env = env_int("PTMI_SORT", -1);
+  const int sort_env = c->tun.sort;
   const bool sort = sort_env >= 0 ? sort_env != 0 : c->material_classes > 1;
 
   // k_shade's grid: as many blocks per CU as the variant's registers and LDS admit (the progressive-mode variants need 79 VGPRs since
   // the build dropped the SLP vectoriser: 6 blocks = 6 waves per SIMD; the importance-sampling ones 93: 5) — asked of the runtime once per variant
   const bool shade_multi = rc.num_samples > 1;
-  int shade_bpc = env_int("PTMI_SHADE_BLOCKS_PER_CU", 0);
+  int shade_bpc = c->tun.shade_blocks_per_cu;
   if (shade_bpc <= 0) {
     int& cached = c->shade_blocks_per_cu[(p.importance_sampling ? 8 : 0) | (sort ? 4 : 0) | (c->counters ? 2 : 0) | (shade_multi ? 1 : 0)];
     if (cached == 0) {
@@ -859,7 +951,7 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   // queues of at most this many slots are traced to the end by one k_tail launch instead of a k_bvh + k_shade pair per bounce
   // (a whole small batch — a lone 1080p frame — at step 0; later steps hand over only their thin ends: on deep trees a lane-per-path
   // wave waits for its longest traversal, and the wavefront kernels with their lane refill stay ahead down to ~0.5 Mi slots)
-  const int tail_env = env_int("PTMI_TAIL_LIMIT", -1);
+  const int tail_env = c->tun.tail_limit;
   const uint32_t tail_limit_first = (uint32_t)(tail_env >= 0 ? tail_env : kTailLimitFirst), tail_limit_later = (uint32_t)(tail_env >= 0 ? tail_env : kTailLimitLater);
 
   ScopedSpan whole(c, T_RENDER);
@@ -897,13 +989,7 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
     }
     {
       ScopedSpan sp(c, T_SHADE);
-#define PTMI_LAUNCH_SHADE(IS, SO, CN, MU)                                                                                                                        \
-  do {                                                                                                                                                          \
-    if (!(IS) && !(MU))                                                                                                                                         \
-      hipLaunchKernelGGL((k_shade6<SO, CN>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, c->d_heads.as<uint32_t>(), tot, s == 0 ? 1 : 0); \
-    else                                                                                                                                                        \
-      hipLaunchKernelGGL((k_shade<IS, SO, CN, MU>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, c->d_heads.as<uint32_t>(), tot, s == 0 ? 1 : 0); \
-  } while (0)
+#define PTMI_LAUNCH_SHADE(IS, SO, CN, MU) launch_shade<IS, SO, CN, MU>(c, sgrid, rc, P, ctl + s, tot, s == 0 ? 1 : 0)
 #define PTMI_LAUNCH_SHADE2(IS, SO)                          \
   do {                                                      \
     if (rc.num_samples > 1) {                               \
@@ -1001,6 +1087,7 @@ struct Rccl {
   }
 };
 Rccl g_rccl;
+int g_test_rccl_fail = 0;  // PTMI_TEST_RCCL_FAIL=init|reduce (tests): pretend ncclCommInitAll / the reduce's group failed, so that the fall-back runs on any box
 std::once_flag g_rccl_once;  // two host threads may create multi-device contexts at the same time
 bool rccl_loaded() {
   std::call_once(g_rccl_once, [] { (void)g_rccl.load(); });
@@ -1068,30 +1155,42 @@ int gather_framebuffer(ptmi_ctx* c, float4** out) {
   if (c->use_rccl) {
     // ncclReduce(sendbuff = this device's buffer, recvbuff = the gather buffer on the root, W*H*4 floats, sum, root 0).
     // A group that has been started is always ended — an open group would swallow every later RCCL call of the process —;
-    // the first error inside it is reported after ncclGroupEnd.
-    RCCL_TRY(c, g_rccl.GroupStart());
+    // the first error inside it is noted after ncclGroupEnd.  An RCCL failure does not fail the read-back: the per-device buffers are
+    // untouched partial sums, so the context switches to the peer-copy reduce below for good (reduce_mode 3) and sums them that way.
     std::string first_error;
-    for (size_t i = 0; i <= c->peers.size() && first_error.empty(); i++) {
-      ptmi_ctx* q = i ? c->peers[i - 1] : c;
-      const hipError_t he = hipSetDevice(q->device);
-      if (he != hipSuccess) {
-        first_error = std::string("hipSetDevice: ") + hipGetErrorString(he);
-        break;
+    ncclResult_t gs = g_test_rccl_fail == 2 ? ncclSystemError : g_rccl.GroupStart();
+    if (gs != ncclSuccess) {
+      first_error = std::string("ncclGroupStart: ") + (g_test_rccl_fail == 2 ? "simulated failure (PTMI_TEST_RCCL_FAIL=reduce)" : g_rccl.GetErrorString(gs));
+    } else {
+      for (size_t i = 0; i <= c->peers.size() && first_error.empty(); i++) {
+        ptmi_ctx* q = i ? c->peers[i - 1] : c;
+        const hipError_t he = hipSetDevice(q->device);
+        if (he != hipSuccess) {
+          first_error = std::string("hipSetDevice: ") + hipGetErrorString(he);
+          break;
+        }
+        const ncclResult_t nr = g_rccl.Reduce(q->fb, i ? (void*)q->fb : (void*)g, n4 * 4, ncclFloat, ncclSum, 0, c->comms[i], q->stream);
+        if (nr != ncclSuccess) first_error = std::string("ncclReduce (local device #") + std::to_string(i) + "): " + g_rccl.GetErrorString(nr);
       }
-      const ncclResult_t nr = g_rccl.Reduce(q->fb, i ? (void*)q->fb : (void*)g, n4 * 4, ncclFloat, ncclSum, 0, c->comms[i], q->stream);
-      if (nr != ncclSuccess) first_error = std::string("ncclReduce (local device #") + std::to_string(i) + "): " + g_rccl.GetErrorString(nr);
+      const ncclResult_t ge = g_rccl.GroupEnd();
+      if (first_error.empty() && ge != ncclSuccess) first_error = std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(ge);
     }
-    const ncclResult_t ge = g_rccl.GroupEnd();
-    (void)hipSetDevice(c->device);
-    if (!first_error.empty()) return fail(c, PTMI_ERR_DEVICE, first_error);
-    if (ge != ncclSuccess) return fail(c, PTMI_ERR_DEVICE, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(ge));
-    for (size_t i = 0; i <= c->peers.size(); i++) {
+    hipError_t se = hipSuccess;
+    for (size_t i = 0; i <= c->peers.size() && se == hipSuccess; i++) {  // whatever was enqueued has to drain before anybody reads or re-sums the buffers
       ptmi_ctx* q = i ? c->peers[i - 1] : c;
-      HIP_TRY(c, hipSetDevice(q->device));
-      HIP_TRY(c, hipStreamSynchronize(q->stream));
+      se = hipSetDevice(q->device);
+      if (se == hipSuccess) se = hipStreamSynchronize(q->stream);
     }
-    HIP_TRY(c, hipSetDevice(c->device));
-  } else {
+    (void)hipSetDevice(c->device);
+    if (first_error.empty() && se != hipSuccess) first_error = std::string("after ncclReduce: ") + hipGetErrorString(se);
+    if (!first_error.empty()) {
+      (void)hipGetLastError();
+      c->use_rccl = false;
+      c->reduce_mode = 3;
+      c->reduce_info = "FALLBACK: hipMemcpyPeer + add (" + first_error + ")";
+    }
+  }
+  if (!c->use_rccl) {
     // shards that share this GPU (tests on a one-GPU box), or PTMI_MULTI_REDUCE=copy: peer copy + add kernel
     HIP_TRY(c, hipMemcpyAsync(g, c->fb, bytes, hipMemcpyDeviceToDevice, c->stream));
     const unsigned grid = (unsigned)std::min<size_t>((n4 + kBlock - 1) / kBlock, (size_t)c->num_cus * 8);
@@ -1172,6 +1271,18 @@ void ptmi_default_params(ptmi_params* p) {
   p->light_mix = 0.2f;   // traceRay.wgsl:43,49
 }
 
+int ptmi_device_count(void) {
+  int n = 0;
+  const hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+const char* ptmi_reduce_info(const ptmi_ctx* c) { return c ? c->reduce_info.c_str() : ""; }
+
 int ptmi_create(ptmi_ctx** out, int device_id) {
   if (!out) return fail(nullptr, PTMI_ERR_INVALID_ARG, "ptmi_create: out is null");
   *out = nullptr;
@@ -1189,6 +1300,7 @@ int ptmi_create(ptmi_ctx** out, int device_id) {
   c->device = device_id;
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   ptmi_default_params(&c->prm);
+  load_tuning(c);
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     delete c;
@@ -1217,6 +1329,10 @@ int ptmi_create_multi(ptmi_ctx** out, const int* device_ids, int n_devices) {
     c->peers.push_back(q);
     for (int j = 0; j < i; j++) distinct = distinct && device_ids[j] != device_ids[i];
   }
+  if (!distinct) {
+    c->shares_device = true;
+    for (ptmi_ctx* q : c->peers) q->shares_device = true;
+  }
   // The reduce: RCCL whenever every shard has a GPU of its own (a communicator cannot hold one GPU twice); shards that
   // share a GPU are summed by a kernel.  PTMI_MULTI_REDUCE=copy forces the peer-copy path, =rccl forces RCCL even for a
   // single device (a one-rank communicator: exercises the library on a one-GPU box).
@@ -1227,17 +1343,48 @@ int ptmi_create_multi(ptmi_ctx** out, const int* device_ids, int n_devices) {
     ptmi_destroy(c);
     return fail(nullptr, PTMI_ERR_UNSUPPORTED, "PTMI_MULTI_REDUCE=rccl needs distinct device ids (an RCCL communicator cannot hold a GPU twice)");
   }
-  if (c->use_rccl) {
-    if (!rccl_loaded()) {
-      ptmi_destroy(c);
-      return fail(nullptr, PTMI_ERR_DEVICE, "ptmi_create_multi: cannot load librccl (" + g_rccl.why + "); set PTMI_RCCL_LIB, or PTMI_MULTI_REDUCE=copy for peer copies instead");
+  // Peer access between the root and every other device, both ways (the peer-copy reduce reads the peers' buffers from the root; RCCL sets up
+  // its own).  Not fatal when refused: hipMemcpyPeerAsync then stages through the host — slower, same bytes.
+  if (distinct && n_devices > 1) {
+    for (ptmi_ctx* q : c->peers) {
+      for (int dir = 0; dir < 2; dir++) {
+        const int from = dir ? q->device : c->device, to = dir ? c->device : q->device;
+        int can = 0;
+        if (hipSetDevice(from) != hipSuccess || hipDeviceCanAccessPeer(&can, from, to) != hipSuccess || !can) continue;
+        const hipError_t pe = hipDeviceEnablePeerAccess(to, 0);
+        if (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) c->peer_links++;
+        (void)hipGetLastError();
+      }
     }
-    c->comms.assign((size_t)n_devices, nullptr);
-    ncclResult_t nr = g_rccl.CommInitAll(c->comms.data(), n_devices, device_ids);
-    if (nr != ncclSuccess) {
-      c->comms.clear();
-      ptmi_destroy(c);
-      return fail(nullptr, PTMI_ERR_DEVICE, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(nr));
+    (void)hipSetDevice(c->device);
+  }
+  const char* tf = getenv("PTMI_TEST_RCCL_FAIL");
+  g_test_rccl_fail = !tf ? 0 : !strcmp(tf, "init") ? 1 : !strcmp(tf, "reduce") ? 2 : 0;
+  c->reduce_mode = n_devices > 1 || force_rccl ? 2 : 0;
+  c->reduce_info = n_devices > 1 ? (distinct ? "hipMemcpyPeer + add (PTMI_MULTI_REDUCE=copy)" : "add kernel (shards share a GPU)") : "single device";
+  if (c->use_rccl) {
+    // The RCCL path has to be able to fail without taking the context with it: if the library cannot be loaded or the communicators cannot be
+    // made, the reduce falls back to peer copies + an add kernel (bit-identical: every pixel is non-zero in one buffer) and says so.
+    std::string why;
+    if (!rccl_loaded()) {
+      why = "cannot load librccl (" + g_rccl.why + "); set PTMI_RCCL_LIB";
+    } else {
+      c->comms.assign((size_t)n_devices, nullptr);
+      const ncclResult_t nr = g_test_rccl_fail == 1 ? ncclSystemError : g_rccl.CommInitAll(c->comms.data(), n_devices, device_ids);
+      if (nr != ncclSuccess) {
+        why = std::string("ncclCommInitAll: ") + (g_test_rccl_fail == 1 ? "simulated failure (PTMI_TEST_RCCL_FAIL=init)" : g_rccl.GetErrorString(nr));
+        c->comms.clear();
+        (void)hipGetLastError();
+        (void)hipSetDevice(c->device);
+      }
+    }
+    if (why.empty()) {
+      c->reduce_mode = 1;
+      c->reduce_info = "ncclReduce over " + std::to_string(n_devices) + " device" + (n_devices > 1 ? "s" : "") + " (RCCL, xGMI)";
+    } else {
+      c->use_rccl = false;
+      c->reduce_mode = 3;
+      c->reduce_info = "FALLBACK: hipMemcpyPeer + add (" + why + ")";
     }
   }
   apply_shard(c);
@@ -1267,8 +1414,11 @@ void ptmi_destroy(ptmi_ctx* c) {
   for (DBuf* b : {&c->d_quad_unit_n, &c->d_spheres, &c->d_sphere_info, &c->d_quads, &c->d_quad_mat, &c->d_tris, &c->d_pretri, &c->d_trinorm, &c->d_meshes, &c->d_xforms,
                   &c->d_mats, &c->d_pairs, &c->d_leaf_table, &c->d_fb_own, &c->d_q0[0], &c->d_q0[1], &c->d_q1[0], &c->d_q1[1], &c->d_q2[0],
                   &c->d_q2[1], &c->d_tp[0], &c->d_tp[1], &c->d_hm[0], &c->d_hm[1], &c->d_uv, &c->d_acc, &c->d_pixsum, &c->d_touched, &c->d_ctl, &c->d_totals,
-                  &c->d_scratch, &c->d_spill, &c->d_heads, &c->d_fb_gather, &c->d_fb_stage, &c->d_bvh_rows, &c->d_diag[0], &c->d_diag[1], &c->d_diag[2], &c->d_diag[3]})
+                  &c->d_scratch, &c->d_spill, &c->d_heads, &c->d_fb_gather, &c->d_fb_stage, &c->d_bvh_rows})
     b->release();
+#ifdef PTMI_EXPERIMENTS
+  for (DBuf& b : c->d_diag) b.release();
+#endif
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c->worker;
   delete c;
@@ -1289,6 +1439,17 @@ int ptmi_set_params(ptmi_ctx* c, const ptmi_params* p) {
   for (ptmi_ctx* q : c->peers) {
     q->prm = *p;
     q->S.tmin = p->tmin;
+    q->ahead.valid = false;
+  }
+  return PTMI_OK;
+}
+
+int ptmi_reload_tuning(ptmi_ctx* c) {
+  if (!c) return PTMI_ERR_INVALID_ARG;
+  load_tuning(c);
+  c->ahead.valid = false;
+  for (ptmi_ctx* q : c->peers) {
+    load_tuning(q);
     q->ahead.valid = false;
   }
   return PTMI_OK;
@@ -1333,10 +1494,17 @@ static int upload_commit(ptmi_ctx* c, int which, const void* data, size_t bytes,
         return fail(c, PTMI_ERR_DEVICE, std::string("ptmi_upload(triangles): ") + hipGetErrorString(e) + " — the triangle buffer is now empty; upload it again");
       }
       c->n_tris_uploaded = bytes / 96;
+      c->bvh_dev_stale = true;  // (meaningful only while bvh_on_device: mesh-order triangles under a tree built over leaf-order ones)
       break;
     }
-    case PTMI_BUF_MESHES: c->h_meshes.assign((const int32_t*)data, (const int32_t*)data + bytes / 4); break;
-    case PTMI_BUF_TRANSFORMS: c->h_xforms.assign(f, f + bytes / 4); break;
+    case PTMI_BUF_MESHES:
+      c->h_meshes.assign((const int32_t*)data, (const int32_t*)data + bytes / 4);
+      c->bvh_dev_stale = true;  // the boxes were made with the old meshes' transform ids
+      break;
+    case PTMI_BUF_TRANSFORMS:
+      c->h_xforms.assign(f, f + bytes / 4);
+      c->bvh_dev_stale = true;  // world-space boxes of the old transforms
+      break;
     case PTMI_BUF_MATERIALS: c->h_mats.assign(f, f + bytes / 4); break;
     case PTMI_BUF_BVH:
       c->h_bvh.assign(f, f + bytes / 4);
@@ -1392,7 +1560,9 @@ static int build_scene_bvh_one(ptmi_ctx* c) {
     c->scene_dirty = true;
     return PTMI_OK;
   }
-  if (n > ((size_t)1 << 27)) return fail(c, PTMI_ERR_UNSUPPORTED, "ptmi_build_scene_bvh: more than 2^27 triangles");
+  // node and primitive ids travel as f32 in the reference's rows (lib/BVH/bvhBuilder.js:45,49) and come back out of them when the pair records are
+  // made: exact only below 2^24 = 2n - 1 nodes
+  if (n > ((size_t)1 << 23)) return fail(c, PTMI_ERR_UNSUPPORTED, "ptmi_build_scene_bvh: more than 2^23 triangles (node ids are f32 in the BVH rows, exact below 2^24)");
   const int n_mesh = (int)(c->h_meshes.size() / 4), n_xf = (int)(c->h_xforms.size() / 32);
   DBuf rows, tris2;
   hipError_t e = rows.ensure((2 * n - 1) * 48);
@@ -1419,6 +1589,7 @@ static int build_scene_bvh_one(ptmi_ctx* c) {
   c->d_bvh_rows.release();
   c->d_bvh_rows = rows;
   c->bvh_on_device = true;
+  c->bvh_dev_stale = false;
   c->bvh_dev_prims = n;
   c->bvh_dev_depth = depth;
   c->h_bvh.clear();
@@ -1526,7 +1697,7 @@ static int render_frame_one(ptmi_ctx* c, const float* u) {
     return PTMI_OK;
   }
   int batch = 1;
-  if (c->static_streak >= 2 && !c->counters && c->timing == 0 && env_int("PTMI_RENDER_AHEAD", 1) != 0) {
+  if (c->static_streak >= 2 && !c->counters && c->timing == 0 && c->tun.render_ahead) {
     const size_t npix = std::max<size_t>(1, count_local((uint32_t)c->W * (uint32_t)c->H, c->rank, c->world, c->tile));
     batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)c->ahead_batch, ((size_t)1 << 29) / npix));
     c->ahead_batch = std::min(64, c->ahead_batch * 2);  // 8, 16, 32, 64 frames while the camera stays put
@@ -1565,7 +1736,7 @@ static int render_one(ptmi_ctx* c, const float* view16, uint32_t first_frame, ui
   // = 80 of the 288 GB).  Every k_bvh launch ends with a tail as long as its longest ray (~2 ms per step on an 871 k-triangle
   // tree, whatever the batch size: configs[2] gains 13 % from 64 -> 128 frames), and the sparse Russian-roulette steps and
   // the launches are amortised over more rays too.  PTMI_PATH_BUDGET_LOG2 overrides (tests, smaller boards).
-  const int budget_log2 = std::max(16, std::min(31, env_int("PTMI_PATH_BUDGET_LOG2", 29)));
+  const int budget_log2 = c->tun.path_budget_log2;
   uint32_t F = c->prm.frames_in_flight > 0 ? (uint32_t)c->prm.frames_in_flight : (uint32_t)std::max<size_t>(1, std::min<size_t>(1024, ((size_t)1 << budget_log2) / npix));
   size_t max_f = std::max<size_t>(1, ((size_t)1 << 31) / npix);  // slot indices (paths + 1/8 + holes) stay below 2^32
   F = (uint32_t)std::min<size_t>(F, max_f);
@@ -1742,6 +1913,8 @@ static int get_stats_one(ptmi_ctx* c, ptmi_stats* out) {
     if (t[15]) return fail(c, PTMI_ERR_STATE, "internal: a step's queue outgrew its buffer (paths were dropped)");
   }
   c->stats.devices = 1;
+  c->stats.reduce_mode = (uint64_t)c->reduce_mode;
+  c->stats.peer_links = (uint64_t)c->peer_links;
   *out = c->stats;
   return PTMI_OK;
 }
@@ -1773,7 +1946,10 @@ static int reset_stats_one(ptmi_ctx* c) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_spans(c);
+  const uint64_t ps = c->stats.placement_sets;  // facts about the context's allocation, not counters of the interval
+  const double pm = c->stats.placement_ms;
   memset(&c->stats, 0, sizeof c->stats);
+  c->stats.placement_sets = ps, c->stats.placement_ms = pm;
   if (c->d_totals.p) HIP_TRY(c, hipMemset(c->d_totals.p, 0, 16 * sizeof(unsigned long long)));
   return PTMI_OK;
 }

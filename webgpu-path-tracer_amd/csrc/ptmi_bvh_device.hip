@@ -457,6 +457,7 @@ int ptmi_bvhdev_make_pairs(void* stream_, const float* d_rows, uint32_t nn, floa
   }
 }
 
+#ifdef PTMI_EXPERIMENTS
 // PTMI_DIAG_SORT (experiment): device-wide radix sort of (key, slot) pairs; scratch allocated per call
 int ptmi_diag_sort_pairs(void* stream_, uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, uint32_t n) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -473,3 +474,4 @@ int ptmi_diag_sort_pairs(void* stream_, uint32_t* keys_in, uint32_t* keys_out, u
     return (int)hipErrorOutOfMemory;
   }
 }
+#endif  // PTMI_EXPERIMENTS

@@ -459,6 +459,7 @@ DEV void obj_ray_for(const DevScene& S, int mesh, int gid, f3 o, f3 d, ObjRay& r
   r.mesh = mesh;
 }
 
+#ifdef PTMI_EXPERIMENTS  // the first edition of the traversal (rounds 1/2), kept for A/B builds only (_build.build_variant)
 // shaders/common.wgsl:191-222 (the accept/reject part; normal, p and material are reconstructed
 // from (index, u, v) by resolve_hit once the closest hit is final)
 template <bool COUNT>
@@ -487,6 +488,8 @@ DEV void hit_triangle(const DevScene& S, int k, f3 o, f3 d, ObjRay& orr, Closest
   if (COUNT) cn.mat_fetches++;
 }
 
+#endif  // PTMI_EXPERIMENTS
+
 // t-interval of a ray against one box, the closest-independent part of hit_aabb (common.wgsl:246-253):
 // ts = max(tmin, max3(tsmaller)), tb = min3(tbigger); the box passes iff min(closest, tb) > ts.
 DEV void slab(float4 lo, float4 hi, f3 o, f3 inv, float tmin, float& ts, float& tb) {
@@ -498,6 +501,7 @@ DEV void slab(float4 lo, float4 hi, f3 o, f3 inv, float tmin, float& ts, float& 
   tb = ptm_min(bx, ptm_min(by, bz));
 }
 
+#ifdef PTMI_EXPERIMENTS  // first edition, continued: its stack, its per-lane state and its phases
 template <bool COUNT>
 DEV void visit_leaf(const DevScene& S, uint32_t ref, f3 o, f3 d, ObjRay& orr, Closest& c, Counters& cn) {
   if (ref & REF_MULTI) {  // hitRay.wgsl:59-68 with prim_count != 1 (external BVHs)
@@ -671,6 +675,8 @@ DEV void trav_inner_phase(const DevScene& S, int stack_size, const LaneStack& st
   }
   trav_pop_until_pass(stk, t, cn, COUNT);
 }
+
+#endif  // PTMI_EXPERIMENTS
 
 // ---- second edition of the traversal state machine (k_bvh2) -----------------------------------------------------------
 // Same visits, same outcomes, same counters as trav_inner_phase / trav_leaf_phase / trav_pop_until_pass; what changed is how

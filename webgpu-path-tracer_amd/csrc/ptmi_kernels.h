@@ -132,6 +132,7 @@ constexpr int kLeafBatch = 16;
 constexpr uint32_t kBvhRange = 512;  // slots a wave claims per global atomic (less when the queue is short); round 3: 256..1024 equal within noise, 2048 +1 %, 8192 +6 % (the last ranges are a tail)
 
 
+#ifdef PTMI_EXPERIMENTS  // first edition of k_bvh (rounds 1/2; PTMI_BVH_KERNEL=1 in an experiments build)
 // hitScene, part 2 (hitRay.wgsl:42-110): BVH traversal by persistent, barrier-free waves.
 // One block = one wave, so LDS (the first lds_entries stack entries of every lane, 512 B each, plus a candidate buffer)
 // and the 96-VGPR budget are what limit how many waves a CU holds (20).  A wave claims ranges of queue SLOTS (one global
@@ -263,6 +264,8 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
   if (COUNT) reduce_counters(cn, totals, true);
 }
 
+#endif  // PTMI_EXPERIMENTS
+
 // k_bvh, second edition (round 3).  Same scheduling (persistent single-wave blocks, team counters, flag scan, ballot refill),
 // same per-ray visit order, outcomes and counters; three changes to where the instructions and the round trips go:
 //   * ONE fetch per lane per iteration whatever the lane is about to do — the pair record of its inner node or the pretri record
@@ -275,8 +278,14 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
 template <bool COUNT, bool NOABORT, bool UNIFIED>
 __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads, uint32_t n_teams, int stack_size,
                                                            int lds_entries, int spill_entries, int2* __restrict__ spill, int refill_threshold, int leaf_batch,
-                                                           unsigned long long* __restrict__ totals, uint32_t range_cap, const uint32_t* __restrict__ diag_order,
-                                                           const uint32_t* __restrict__ diag_keys) {
+                                                           unsigned long long* __restrict__ totals, uint32_t range_cap
+#ifdef PTMI_EXPERIMENTS
+                                                           , const uint32_t* __restrict__ diag_order, const uint32_t* __restrict__ diag_keys
+#endif
+) {
+#ifndef PTMI_EXPERIMENTS
+  static_assert(!UNIFIED, "the unified-fetch loop is an experiment (measured and dropped, DESIGN.md / profiles/NOTES_r03.md): build with -DPTMI_EXPERIMENTS");
+#endif
   extern __shared__ int lds_stack[];
   const int lane = lane_id();
   LaneStack2 stk;
@@ -333,12 +342,13 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, 
         }
         uint32_t slot = rb + (uint32_t)lane;
         bool flagged;
-        if (diag_order) {  // PTMI_DIAG_SORT (an experiment): the queue's BVH rays in an explicit, fully sorted order instead of slot order
+#ifdef PTMI_EXPERIMENTS
+        if (diag_order) {  // PTMI_DIAG_SORT: the queue's BVH rays in an explicit, fully sorted order instead of slot order
           flagged = slot < re && diag_keys[slot] != 0xffffffffu;
           if (flagged) slot = diag_order[slot];
-        } else {
+        } else
+#endif
           flagged = slot < re && (P.hin.mat[slot] & HITMAT_BVH) != 0u;
-        }
         const uint64_t fm = __ballot(flagged);
         if (flagged) cand[ncand + lanes_below(fm)] = slot;
         ncand += (uint32_t)__popcll(fm);
@@ -371,6 +381,7 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, 
     const bool more = ncand > 0 || !(exhausted && rb == re);
     const int min_working = more ? (64 - refill_threshold + 1) : 1;
     int working;
+#ifdef PTMI_EXPERIMENTS
     if (UNIFIED) {
     float4 f0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), f1 = f0, f2 = f0, f3v = f0;
     bool fetched = false;  // f0..f3v hold the pretri record of this lane's pending triangle
@@ -406,8 +417,10 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, 
       node = next;
       working = __popcll(__ballot(node != N_DONE));
     } while (working >= min_working);
-    } else {
-    // Two phases per iteration, each with its own fetch, as in the first edition: the triangle records are the coldest data of the
+    } else
+#endif
+    {
+    // Two phases per iteration, each with its own fetch: the triangle records are the coldest data of the
     // scene, and a wave waits for the slowest lane of a fetch — mixing them into every pair fetch (UNIFIED) made every wait a slow one
     // (configs[3]: 581 ms against 514 per 128 spp although it issues 11 % fewer vector and 46 % fewer memory instructions).
     do {
@@ -436,6 +449,7 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, 
   if (COUNT) reduce_counters(cn, totals, true);
 }
 
+#ifdef PTMI_EXPERIMENTS
 // PTMI_DIAG_SORT: sort key of every slot of a queue — 0xffffffff for slots k_bvh has nothing to do for; else direction octant and a 27-bit
 // Morton code of the origin in [-1.5, 1.5]^3 (mode 1: octant major, mode 2: origin major, mode 3: origin only).  Experiment only.
 DEV uint32_t diag_spread3(uint32_t v) {  // 9 bits -> every third bit
@@ -461,6 +475,7 @@ __global__ __launch_bounds__(kBlock) void k_diag_sort_keys(Paths P, const StepCt
     vals[slot] = slot;
   }
 }
+#endif  // PTMI_EXPERIMENTS
 
 // What a surviving path carries into the next step's queue.
 struct NewState {

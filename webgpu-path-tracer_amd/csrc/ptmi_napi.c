@@ -505,6 +505,10 @@ static napi_value js_stats(napi_env env, napi_callback_info info) {
   set_f64(env, o, "devices", (double)s.devices);
   set_f64(env, o, "bvh_node_visits", (double)s.bvh_node_visits);
   set_f64(env, o, "bvh_mat_fetches", (double)s.bvh_mat_fetches);
+  set_f64(env, o, "reduce_mode", (double)s.reduce_mode);
+  set_f64(env, o, "peer_links", (double)s.peer_links);
+  set_f64(env, o, "placement_sets", (double)s.placement_sets);
+  set_f64(env, o, "placement_ms", s.placement_ms);
   return o;
 }
 

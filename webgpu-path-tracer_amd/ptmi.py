@@ -19,6 +19,7 @@ SYMBOLS = [
     "ptmi_framebuffer_device_ptr", "ptmi_bind_framebuffer", "ptmi_stream", "ptmi_resolve_rgba8", "ptmi_set_counters",
     "ptmi_set_timing", "ptmi_get_stats", "ptmi_reset_stats", "ptmi_trace", "ptmi_math_eval", "ptmi_selftest", "ptmi_build_bvh",
     "ptmi_build_bvh_sah", "ptmi_build_bvh_device", "ptmi_build_scene_bvh", "ptmi_read_scene_buffer", "ptmi_obj_parse", "ptmi_free",
+    "ptmi_device_count", "ptmi_reduce_info", "ptmi_reload_tuning",
 ]
 
 
@@ -35,7 +36,8 @@ class Stats(ctypes.Structure):
         "rays", "paths", "node_visits", "tri_tests", "sphere_tests", "quad_tests", "mat_fetches", "frames",
         "intersect_launches", "shade_launches", "bvh_node_visits", "bvh_mat_fetches")] + [
         (n, ctypes.c_double) for n in ("render_ms", "intersect_ms", "shade_ms", "other_ms", "prims_ms", "bvh_ms", "generate_ms", "accumulate_ms")] + [
-        (n, ctypes.c_uint64) for n in ("generate_launches", "accumulate_launches", "devices")] + [("tail_ms", ctypes.c_double), ("tail_launches", ctypes.c_uint64)]
+        (n, ctypes.c_uint64) for n in ("generate_launches", "accumulate_launches", "devices")] + [("tail_ms", ctypes.c_double), ("tail_launches", ctypes.c_uint64)] + [
+        (n, ctypes.c_uint64) for n in ("reduce_mode", "peer_links", "placement_sets")] + [("placement_ms", ctypes.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -113,6 +115,10 @@ def load_library(build=False):
     L.ptmi_obj_parse.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(vp), ctypes.POINTER(sz)]
     L.ptmi_free.argtypes = [vp]
     L.ptmi_free.restype = None
+    L.ptmi_device_count.restype = i32
+    L.ptmi_reduce_info.restype = ctypes.c_char_p
+    L.ptmi_reduce_info.argtypes = [vp]
+    L.ptmi_reload_tuning.argtypes = [vp]
     _lib = L
     return L
 
@@ -269,6 +275,14 @@ class Context:
         out = np.empty((self.height, self.width, 4), np.float32)
         self._ck(self.lib.ptmi_read_framebuffer(self.h, _ptr(out), out.nbytes))
         return out
+
+    def reduce_info(self):
+        """One line about how this context sums its devices' buffers (RCCL, add kernel, or the FALLBACK after an RCCL failure)."""
+        return self.lib.ptmi_reduce_info(self.h).decode()
+
+    def reload_tuning(self):
+        """Re-read the PTMI_* tuning variables (they are read once, at creation)."""
+        self._ck(self.lib.ptmi_reload_tuning(self.h))
 
     def reduce_framebuffer(self):
         """The one collective of a multi-device render (sum of the per-device buffers on the first device); a sync on one device."""
