@@ -554,6 +554,9 @@ int prepare_scene(ptmi_ctx* c) {
   S.root_hi = make_float4(root_hi[0], root_hi[1], root_hi[2], root_hi[3]);
   S.n_spheres = n_sph, S.n_quads = n_quad, S.n_tris = n_tri, S.n_meshes = n_mesh, S.n_xforms = n_xf, S.n_mats = n_mat, S.n_nodes = n_node;
   S.light_quad = light;
+  S.uniform_gid = n_mesh > 0 ? c->h_meshes[2] : -1;
+  for (int i = 1; i < n_mesh; i++)
+    if (c->h_meshes[4 * (size_t)i + 2] != S.uniform_gid) S.uniform_gid = -1;
   S.tmin = c->prm.tmin;
   c->scene_dirty = false;
   return PTMI_OK;
@@ -742,7 +745,7 @@ void load_tuning(ptmi_ctx* c) {
 
 // hitScene, part 2 for the step's queue (k_bvh).  Part 1 has already been run by whoever created the rays (k_generate,
 // k_shade); ptmi_trace's rays come from the host, so it asks for k_prims first.
-int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_items, bool with_prims) {
+int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_items, bool with_prims, const RenderConst* first_rc = nullptr) {
   unsigned long long* tot = c->d_totals.as<unsigned long long>();
   const uint32_t pgrid = std::max<uint32_t>(1, std::min<uint32_t>((max_items + kBlock - 1) / kBlock, (uint32_t)c->num_cus * 32));
   if (with_prims) {
@@ -757,7 +760,7 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
   const uint32_t* diag_order = nullptr;
   const uint32_t* diag_keys = nullptr;
   const int diag = c->tun.diag_sort;
-  if (diag > 0 && !with_prims) {
+  if (diag > 0 && !with_prims && !first_rc) {  // (not on step 0's queue: it does not store the origins the keys are made of)
     for (int k = 0; k < 4; k++) HIP_TRY(c, c->d_diag[k].ensure((size_t)max_items * 4));
     hipLaunchKernelGGL(k_diag_sort_keys, dim3(pgrid), dim3(kBlock), 0, c->stream, P, ctl, diag, c->d_diag[0].as<uint32_t>(), c->d_diag[2].as<uint32_t>(), max_items);
     uint32_t nq = 0;
@@ -801,15 +804,18 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
   HIP_TRY(c, c->d_spill.ensure(std::max<size_t>(16, (size_t)std::max<uint32_t>(grid, (uint32_t)c->num_cus * 32) * (size_t)se * 64 * sizeof(int2))));
   const int thr = tun.refill, leaf_batch = tun.leaf_batch;
   const uint32_t range_cap = (uint32_t)tun.bvh_range;
+  // step 0's queue does not store the rays' common origin (k_generate): the kernel is handed cam_origin
+  float4 cam = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (first_rc) cam = make_float4(first_rc->cam_o[0], first_rc->cam_o[1], first_rc->cam_o[2], 1.0f);
 #ifdef PTMI_EXPERIMENTS
   // PTMI_BVH_KERNEL: 1 = the first edition of the traversal kernel (rounds 1/2), 2 = second edition with one unified fetch per iteration,
   // 3 (default) = the shipped kernel — for A/B runs
 #define PTMI_LAUNCH_BVH_K1(KERNEL)                                                                                                                                    \
   hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), n_teams, c->prm.stack_size, le, se, c->d_spill.as<int2>(), thr, \
-                     leaf_batch, tot)
+                     leaf_batch, tot, cam)
 #define PTMI_LAUNCH_BVH_K(KERNEL)                                                                                                                                     \
   hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), n_teams, c->prm.stack_size, le, se, c->d_spill.as<int2>(), thr, \
-                     leaf_batch, tot, range_cap, diag_order, diag_keys)
+                     leaf_batch, tot, range_cap, cam, diag_order, diag_keys)
 #define PTMI_LAUNCH_BVH(CNT, NA)                                       \
   do {                                                                 \
     if (edition == 1) PTMI_LAUNCH_BVH_K1((k_bvh<CNT, NA>));           \
@@ -819,7 +825,7 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
 #else
 #define PTMI_LAUNCH_BVH(CNT, NA)                                                                                                                                       \
   hipLaunchKernelGGL((k_bvh2<CNT, NA, false>), dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), n_teams, c->prm.stack_size, le, se, \
-                     c->d_spill.as<int2>(), thr, leaf_batch, tot, range_cap)
+                     c->d_spill.as<int2>(), thr, leaf_batch, tot, range_cap, cam)
 #endif
   if (c->counters) {
     if (noabort) PTMI_LAUNCH_BVH(true, true);
@@ -891,6 +897,10 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   rc.W = (float)c->W;
   rc.H = (float)c->H;
   memcpy(rc.view, view16, 64);
+  {  // cam_origin = (view * vec4(0,0,0,1)).xyz, the column-weighted sum of SURVEY.md §8a-W in f32 (ptmi_device.h: cam_origin)
+    const float* m = rc.view;
+    for (int k = 0; k < 3; k++) rc.cam_o[k] = ((m[k] * 0.0f + m[4 + k] * 0.0f) + m[8 + k] * 0.0f) + m[12 + k] * 1.0f;
+  }
   rc.fov_factor = (float)(1.0 / std::tan((double)p.fov_degrees * (3.14159265358979323846 / 180.0) / 2.0));  // main.wgsl:7, folded in f64
   rc.bg[0] = p.background[0], rc.bg[1] = p.background[1], rc.bg[2] = p.background[2];
   rc.max_bounces = p.max_bounces;
@@ -984,7 +994,7 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
       if (s == 0 && total <= tail_limit) break;
     }
     {
-      int lr = launch_intersect(c, P, ctl + s, bound, false);
+      int lr = launch_intersect(c, P, ctl + s, bound, false, s == 0 ? &rc : nullptr);
       if (lr) return lr;
     }
     {
@@ -1997,6 +2007,21 @@ int ptmi_trace(ptmi_ctx* c, size_t n, const float* rays6, uint32_t* rng_inout, p
     for (size_t i = 0; i < n; i++) memcpy(&rng_inout[i], &so[4 * i + 3], 4);
   return PTMI_OK;
 }
+
+#ifdef PTMI_LANE_TALLY
+// measurement builds only (tools/shade_lanes.py): {visits, lanes} per tally point of k_shade since the last reset
+int ptmi_lane_tally(ptmi_ctx* c, uint64_t* out, int n_points, int reset) {
+  if (!c || !out || n_points < 0 || n_points > kLaneTallies) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_lane_tally: bad argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lane_tally), (size_t)n_points * 16));
+  if (reset) {
+    static const unsigned long long zeros[kLaneTallies * 2] = {0};
+    HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_lane_tally), zeros, sizeof zeros));
+  }
+  return PTMI_OK;
+}
+#endif
 
 int ptmi_selftest(ptmi_ctx* c, int which, uint64_t* mismatches, uint32_t* first_bad_bits) {
   if (!c || !mismatches) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_selftest: null argument");

@@ -15,6 +15,37 @@
 
 namespace ptmi {
 
+// ---- lane tallies (measurement builds only: -DPTMI_LANE_TALLY, tools/shade_lanes.py) ------------------------------------------------------
+// LT(k) at the head of a region of k_shade's code counts how often a wave enters it and with how many lanes of its exec mask set:
+// where do the idle lanes of the kernel's instructions go?  Tallied in LDS per block, flushed by k_shade alone (the other kernels that share
+// these device functions tally into LDS that nobody reads).  The `; LT_MARK k` comment lands in the ISA, so that tools/shade_lanes.py can
+// attribute static instruction counts to the same regions.  Without the macro LT() is nothing.
+#ifdef PTMI_LANE_TALLY
+constexpr int kLaneTallies = 48;
+__shared__ uint32_t s_lane_tally[kLaneTallies * 2];  // {visits, lanes} per point
+__device__ unsigned long long g_lane_tally[kLaneTallies * 2];
+template <int K>
+DEV void lane_tally() {
+  static_assert(K >= 0 && K < kLaneTallies, "tally point out of range");
+  const unsigned long long m = __ballot(1);
+  asm volatile("; LT_MARK %0" ::"n"(K));
+  if (__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0u) {
+    atomicAdd(&s_lane_tally[2 * K], 1u);
+    atomicAdd(&s_lane_tally[2 * K + 1], (uint32_t)__popcll(m));
+  }
+}
+#define LT(k) lane_tally<k>()
+#else
+#define LT(k) ((void)0)
+#endif
+// tally points
+enum : int {
+  LT_GROUP = 0, LT_VALID = 1, LT_MISS = 2, LT_HIT = 3, LT_RH_SPHERE = 4, LT_RH_VOLUME = 5, LT_RH_QUAD = 6, LT_RH_TRI = 7, LT_MS_LAMBERT = 8, LT_MS_MIRROR = 9,
+  LT_MS_GLASS = 10, LT_MS_ISO = 11, LT_RR = 12, LT_ACC_CONT = 13, LT_END_SAMPLE = 14, LT_END_CHANGES = 15, LT_FLUSH = 16, LT_QUAD_LOOP = 17, LT_QUAD_FRONT = 18,
+  LT_QUAD_DENOM = 19, LT_QUAD_T = 20, LT_QUAD_ACCEPT = 21, LT_ROOT_BOX = 22, LT_MISS_SHORTCUT = 23, LT_KEEP = 24, LT_DIV3_SLOW = 25, LT_RCP_SLOW = 26, LT_SQRT_SLOW = 27,
+  LT_SPHERE_LOOP = 28, LT_IS_LIGHT = 29, LT_STAGE = 30
+};
+
 // ---- constants of shaders/header.wgsl:1-13,37 (abstract-float consts folded in f64, rounded once) ----
 constexpr float kPi = 3.14159265358979323846;
 constexpr float kTwoPi = 2.0 * 3.14159265358979323846;
@@ -48,7 +79,10 @@ DEV f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
 // multiplication as they do out of the division).  The two exceptions are redone with the real division: a divisor that is
 // 0, inf or NaN (the Newton steps turn those into NaN), and a SUBNORMAL quotient, where exact ties exist (the grid is
 // coarser than the quotient's precision) and a tie must not be broken by the 2^-51.
-__device__ __attribute__((noinline)) f3 div3_ieee(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }  // the rare path, kept out of line
+__device__ __attribute__((noinline)) f3 div3_ieee(f3 a, float s) {
+  LT(LT_DIV3_SLOW);
+  return mk3(a.x / s, a.y / s, a.z / s);
+}  // the rare path, kept out of line
 DEV f3 operator/(f3 a, float s) {
   const double ds = (double)s;
   double r = __builtin_amdgcn_rcp(ds);  // 2^-24.4
@@ -76,8 +110,14 @@ DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 #endif
 // The out-of-range path: a call where registers are plentiful and code size matters (k_shade: inlining it cost configs[1] 4 %),
 // inline inside k_bvh, whose triangle test pays for the registers saved around a call (configs[3]: 4 %).
-__device__ __attribute__((noinline)) float rcp_ieee_slow(float x) { return 1.0f / x; }
-__device__ __attribute__((noinline)) float sqrt_ieee_slow(float x) { return __builtin_sqrtf(x); }
+__device__ __attribute__((noinline)) float rcp_ieee_slow(float x) {
+  LT(LT_RCP_SLOW);
+  return 1.0f / x;
+}
+__device__ __attribute__((noinline)) float sqrt_ieee_slow(float x) {
+  LT(LT_SQRT_SLOW);
+  return __builtin_sqrtf(x);
+}
 DEV float rcp_core(float x) {  // valid for |x| in [2^-100, 2^100]
   const float y0 = __builtin_amdgcn_rcpf(x);
   const float y1 = __builtin_fmaf(__builtin_fmaf(-x, y0, 1.0f), y0, y0);
@@ -146,8 +186,7 @@ DEV float4 mat_mul(const float4* __restrict__ m, f3 v, float w) {
   return r;
 }
 // transpose(m) * (v, 0): component i is the dot of column i with (v, 0)
-DEV f3 mat_mul_transposed_dir(const float4* __restrict__ m, f3 v) {
-  float4 c0 = m[0], c1 = m[1], c2 = m[2];
+DEV f3 mat_mul_transposed_dir(float4 c0, float4 c1, float4 c2, f3 v) {
   return mk3(((c0.x * v.x + c0.y * v.y) + c0.z * v.z) + c0.w * 0.0f, ((c1.x * v.x + c1.y * v.y) + c1.z * v.z) + c1.w * 0.0f,
              ((c2.x * v.x + c2.y * v.y) + c2.z * v.z) + c2.w * 0.0f);
 }
@@ -192,6 +231,8 @@ struct DevScene {
   float4 root_lo, root_hi;  // root box; root_lo.w = root's child ref
   int n_spheres, n_quads, n_tris, n_meshes, n_xforms, n_mats, n_nodes;
   int light_quad;  // first quad with emission.x > 0 (common.wgsl:258-269), -1 if none
+  int uniform_gid;  // the transform index all meshes share (one mesh: every configuration of BASELINE.json), -1 if they differ: a triangle hit's
+                    // normal matrix then comes through the scalar cache with the hit's other data instead of one dependent VMEM round trip later
   float tmin;      // ray_tmin (header.wgsl:37; ptmi_params.tmin, 0.000001 by default)
 };
 
@@ -212,9 +253,10 @@ constexpr uint32_t HITMAT_HOLE = (7u << HITMAT_BIN_SHIFT) | 0x0ffffffeu;        
 constexpr uint32_t HITMAT_BVH = 0x80000000u;   // flag: the ray entered the root box, k_bvh still has to traverse it
 
 struct Slots {     // 48 bytes of live state per slot
-  float4* q0;      // {origin.xyz, randState bits}
+  float4* q0;      // {origin.xyz, randState bits}; STEP 0's queue (k_generate's output) holds the randState alone, 4 bytes per slot at the start of the
+                   // same buffer: every camera ray starts at cam_origin (rng0_of / load_slot)
   float4* q1;      // {dir.xyz, path id bits — PID_HOLE = no path}
-  float4* q2;      // {throughput.xyz, bounce index bits}
+  float4* q2;      // {throughput.xyz, bounce index | kAccWritten (ptmi_kernels.h: the path has stored its acc_radiance before)}
 };
 struct HitBuf {    // hitScene's result for the ray in the same slot: 12 bytes, plus 8 more for a triangle hit
   float2* tp;      // {t, kind<<28 | index}
@@ -248,6 +290,7 @@ DEV uint32_t* tally_line(unsigned long long* totals, uint32_t k) {
 struct RenderConst {
   float W, H;
   float view[16];
+  float cam_o[3];  // cam_origin (main.wgsl:8), see cam_origin()
   float fov_factor;
   float bg[3];
   int max_bounces;
@@ -271,6 +314,12 @@ DEV uint32_t local_to_pixel(const RenderConst& rc, uint32_t j) {
   uint32_t tl = j / (uint32_t)rc.tile, within = j - tl * (uint32_t)rc.tile;
   return (tl * (uint32_t)rc.world + (uint32_t)rc.rank) * (uint32_t)rc.tile + within;
 }
+
+// cam_origin = (view * (0,0,0,1)).xyz  (main.wgsl:8): the origin of EVERY camera ray of a frame, so step 0's queue does not store it — whoever
+// reads that queue (k_shade / k_tail with `first`, k_bvh with its `cam` argument) takes it from here.  Evaluated once per batch by the host
+// (render_batch: ((m0*0 + m4*0) + m8*0) + m12*1 per component, the shader's mat4 * vec4 in f32 — multiplications by 0 and 1 and additions,
+// the same IEEE results on the host as on the device) instead of occupying twelve scalar registers with the view matrix in every kernel.
+DEV f3 cam_origin(const RenderConst& rc) { return mk3(rc.cam_o[0], rc.cam_o[1], rc.cam_o[2]); }
 
 // shaders/main.wgsl:3-8 + shaders/shootRay.wgsl:5-60: jittered camera ray for sample k of a pixel
 DEV void camera_ray(const RenderConst& rc, uint32_t pix, int k, uint32_t& rng, f3& o, f3& d) {
@@ -296,9 +345,7 @@ DEV void camera_ray(const RenderConst& rc, uint32_t pix, int k, uint32_t& rng, f
   float dw = ((m[3] * a + m[7] * b) + m[11] * nf) + m[15] * 0.0f;
   float len = sqrt_exact(((dx * dx + dy * dy) + dz * dz) + dw * dw);  // normalize() of the vec4, then .xyz
   d = mk3(dx, dy, dz) / len;
-  // cam_origin = (view * (0,0,0,1)).xyz  (main.wgsl:8)
-  o = mk3(((m[0] * 0.0f + m[4] * 0.0f) + m[8] * 0.0f) + m[12] * 1.0f, ((m[1] * 0.0f + m[5] * 0.0f) + m[9] * 0.0f) + m[13] * 1.0f,
-          ((m[2] * 0.0f + m[6] * 0.0f) + m[10] * 0.0f) + m[14] * 1.0f);
+  o = cam_origin(rc);
 }
 
 // Loads whose address is the same for every lane of a wave (primitive tables walked by a wave-uniform loop index):
@@ -355,6 +402,7 @@ DEV void hit_spheres(const DevScene& S, f3 o, f3 d, uint32_t& rng, Closest& c, C
     int2 info = ldu(S.sphere_info + i);
     f3 center = mk3(s0);
     float r = s0.w;
+    LT(LT_SPHERE_LOOP);
     if (COUNT) cn.sphere_tests++;
     if (!info.y) {
       float root;
@@ -394,18 +442,23 @@ DEV void hit_quads(const DevScene& S, f3 o, f3 d, Closest& c, Counters& cn) {
     const float4 q0 = ldu(q), q1 = ldu(q + 1), q2 = ldu(q + 2), q3 = ldu(q + 3), q4 = ldu(q + 4);
     const int qmat = ldu(S.quad_mat + i);
     f3 n = mk3(q3);
+    LT(LT_QUAD_LOOP);
     if (COUNT) cn.quad_tests++;
     if (dot3(d, n) > 0) continue;
+    LT(LT_QUAD_FRONT);
     float denom = dot3(n, d);
     if (ptm_abs(denom) < 1e-8f) continue;
+    LT(LT_QUAD_DENOM);
     float t = (q3.w - dot3(n, o)) / denom;
     if (t <= S.tmin || t >= c.t) continue;
+    LT(LT_QUAD_T);
     f3 isect = o + t * d;
     f3 ph = isect - mk3(q0);
     f3 w = mk3(q4);
     float alpha = dot3(w, cross3(ph, mk3(q2)));
     float beta = dot3(w, cross3(mk3(q1), ph));
     if (alpha < 0 || 1 < alpha || beta < 0 || 1 < beta) continue;
+    LT(LT_QUAD_ACCEPT);
     c.t = t;
     c.prim = (K_QUAD << 28) | (uint32_t)i;
     c.mat = qmat;
@@ -438,6 +491,7 @@ DEV void prims_for_ray(const DevScene& S, f3 o, f3 d, uint32_t& rng, float2& tp,
   bool to_bvh = false;
   if (S.n_nodes > 0) {
     if (COUNT) cn.node_visits++;
+    LT(LT_ROOT_BOX);
     const f3 inv = rcp3_exact(d);  // 1 / ray.dir (hitRay.wgsl:46)
     to_bvh = hit_aabb(S.root_lo, S.root_hi, S.tmin, c.t, o, inv);
   }
@@ -810,10 +864,7 @@ struct TriFetch {
   int gid;
 };
 DEV TriFetch tri_fetch(const DevScene& S, const float2* __restrict__ uvbuf, uint32_t slot, uint32_t prim) {
-  TriFetch f;
-  f.uv = make_float2(0.0f, 0.0f);
-  f.nA = f.nB = f.nC = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  f.gid = 0;
+  TriFetch f;  // (read by resolve_hit's K_TRI branch only: nothing to initialise for the other lanes — 14 moves per group)
   if ((prim >> 28) == K_TRI) {
     const uint32_t idx = prim & 0x0fffffffu;
     f.uv = uvbuf[slot];
@@ -827,8 +878,6 @@ DEV TriFetch tri_fetch(const DevScene& S, const float2* __restrict__ uvbuf, uint
 DEV TriFetch tri_fetch_uv(const DevScene& S, float2 uv, uint32_t prim) {
   TriFetch f;
   f.uv = uv;
-  f.nA = f.nB = f.nC = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  f.gid = 0;
   if ((prim >> 28) == K_TRI) {
     const uint32_t idx = prim & 0x0fffffffu;
     const float4* tn = S.trinorm + 3 * (size_t)idx;
@@ -842,22 +891,34 @@ DEV HitGeom resolve_hit(const DevScene& S, f3 o, f3 d, float t, const TriFetch& 
   uint32_t kind = prim >> 28, idx = prim & 0x0fffffffu;
   g.p = o + t * d;  // at(ray, t)
   if (kind == K_SPHERE) {  // common.wgsl:54-68
+    LT(LT_RH_SPHERE);
     float4 s0 = S.spheres[2 * idx];
     g.n = norm3((g.p - mk3(s0)) / s0.w);
     g.front = dot3(d, g.n) < 0;
     if (!g.front) g.n = -g.n;
   } else if (kind == K_VOLUME) {  // common.wgsl:140-143
+    LT(LT_RH_VOLUME);
     float4 s0 = S.spheres[2 * idx];
     g.n = norm3(g.p - mk3(s0));
     g.front = true;
   } else if (kind == K_QUAD) {  // common.wgsl:176-183: normalize(quad.normal) is a per-quad constant, read from the digest
+    LT(LT_RH_QUAD);
     g.n = mk3(S.quad_unit_n[idx]);
     g.front = dot3(d, g.n) < 0;
     if (!g.front) g.n = -g.n;
   } else {  // K_TRI, common.wgsl:224-237
+    LT(LT_RH_TRI);
     float w = 1.0f - tf.uv.x - tf.uv.y;
     f3 nn = mk3(tf.nA) * w + mk3(tf.nB) * tf.uv.x + mk3(tf.nC) * tf.uv.y;
-    g.n = norm3(mat_mul_transposed_dir(S.xforms + 8 * tf.gid + 4, nn));
+    float4 c0, c1, c2;  // columns 0..2 of the mesh's invModelMatrix
+    if (S.uniform_gid >= 0) {  // one transform for every mesh: a wave-uniform address, known before the triangle's record arrives
+      const float4* m = S.xforms + 8 * S.uniform_gid + 4;
+      c0 = ldu(m), c1 = ldu(m + 1), c2 = ldu(m + 2);
+    } else {
+      const float4* m = S.xforms + 8 * tf.gid + 4;
+      c0 = m[0], c1 = m[1], c2 = m[2];
+    }
+    g.n = norm3(mat_mul_transposed_dir(c0, c1, c2, nn));
     g.front = dot3(d, g.n) < 0;
     if (!g.front) g.n = -g.n;
   }
@@ -966,6 +1027,7 @@ DEV f3 material_scatter(int bin, const Material& m, const HitGeom& g, f3 din, ui
   doSpecular = 0.0f;
   skip_pdf = true;
   if (bin == BIN_LAMBERTIAN) {
+    LT(LT_MS_LAMBERT);
     Onb b = onb_build_from_w(g.n);
     unit_w = b.w;
     f3 diffuse = cosine_sampling_wrt_Z(rng);
@@ -976,9 +1038,11 @@ DEV f3 material_scatter(int bin, const Material& m, const HitGeom& g, f3 din, ui
     skip_pdf = (doSpecular == 1.0f);
     return norm3(mix3(diffuse, specular, doSpecular));
   } else if (bin == BIN_MIRROR) {
+    LT(LT_MS_MIRROR);
     f3 reflected = reflect3(din, g.n);
     return norm3(reflected + m.roughness * uniform_random_in_unit_sphere(rng));
   } else if (bin == BIN_GLASS) {
+    LT(LT_MS_GLASS);
     float ir = m.eta;
     if (g.front) ir = rcp_exact(ir);
     f3 ud = norm3(din);
@@ -992,6 +1056,7 @@ DEV f3 material_scatter(int bin, const Material& m, const HitGeom& g, f3 din, ui
     }
     return norm3(dir);
   } else if (bin == BIN_ISOTROPIC) {
+    LT(LT_MS_ISO);
     float gg = m.specularStrength;
     float cos_hg = (1.0f + gg * gg - ptm_pow(((1.0f - gg * gg) / (1.0f - gg + 2.0f * gg * rand2D(rng))), 2.0f)) / (2.0f * gg);
     float sin_hg = sqrt_exact(1.0f - cos_hg * cos_hg);

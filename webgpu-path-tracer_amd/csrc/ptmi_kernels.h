@@ -38,6 +38,9 @@ DEV void reduce_counters(const Counters& cn, unsigned long long* __restrict__ to
   }
 }
 
+// step 0's queue: the randState of slot g (see Slots::q0)
+DEV uint32_t* rng0_of(const Paths& P) { return reinterpret_cast<uint32_t*>(P.in.q0); }
+
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_generate(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads,
                                                      unsigned long long* __restrict__ totals) {
@@ -56,9 +59,9 @@ __global__ __launch_bounds__(kBlock) void k_generate(DevScene S, RenderConst rc,
     float2 tp = make_float2(0.0f, 0.0f);
     uint32_t hm = HITMAT_MISS;
     if (trace) prims_for_ray<COUNT>(S, o, d, rng, tp, hm, cn);
-    // 44 bytes per path.  What every new path starts with — throughput (1,1,1), bounce 0, acc_radiance 0 — is not stored: step 0's
-    // k_shade is told so (`first`), and acc[pid] counts as zero until P.touched[pid] is set (NUM_SAMPLES == 1).
-    P.in.q0[g] = make_float4(o.x, o.y, o.z, __uint_as_float(rng));
+    // 32 bytes per path.  What every new path starts with — origin = cam_origin, throughput (1,1,1), bounce 0, acc_radiance 0 — is not stored: the
+    // readers of step 0's queue are told so (`first`), and acc[pid] counts as zero until P.touched[pid] is set (NUM_SAMPLES == 1).
+    rng0_of(P)[g] = rng;
     P.in.q1[g] = make_float4(d.x, d.y, d.z, __uint_as_float(pid));
     P.hin.tp[g] = tp;
     P.hin.mat[g] = hm;
@@ -147,7 +150,7 @@ template <bool COUNT, bool NOABORT>
 __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads, uint32_t n_teams, int stack_size,
                                                                                        int lds_entries, int spill_entries, int2* __restrict__ spill,
                                                                                        int refill_threshold, int leaf_batch,
-                                                                                       unsigned long long* __restrict__ totals) {
+                                                                                       unsigned long long* __restrict__ totals, float4 cam) {
   extern __shared__ int lds_stack[];
   const int lane = lane_id();
   LaneStack stk;
@@ -219,7 +222,8 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
         const uint32_t take = min(ncand, want);
         if (!has && k < take) {
           myslot = cand[ncand - 1u - k];
-          float4 r0 = P.in.q0[myslot], r1 = P.in.q1[myslot];
+          float4 r0 = cam, r1 = P.in.q1[myslot];
+          if (cam.w == 0.0f) r0 = P.in.q0[myslot];  // (step 0's queue does not store the common origin)
           float2 h = P.hin.tp[myslot];
           const uint32_t hmat = P.hin.mat[myslot] & HITMAT_WORD;
           t.o = mk3(r0);
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
 template <bool COUNT, bool NOABORT, bool UNIFIED>
 __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads, uint32_t n_teams, int stack_size,
                                                            int lds_entries, int spill_entries, int2* __restrict__ spill, int refill_threshold, int leaf_batch,
-                                                           unsigned long long* __restrict__ totals, uint32_t range_cap
+                                                           unsigned long long* __restrict__ totals, uint32_t range_cap, float4 cam  // cam.w != 0: step 0's queue — every ray starts at cam.xyz
 #ifdef PTMI_EXPERIMENTS
                                                            , const uint32_t* __restrict__ diag_order, const uint32_t* __restrict__ diag_keys
 #endif
@@ -360,9 +364,10 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, 
         const uint32_t take = min(ncand, want);
         if (node == N_DONE && k < take) {
           myslot = cand[ncand - 1u - k];
-          const float4 r0 = P.in.q0[myslot], r1 = P.in.q1[myslot];
+          const float4 r1 = P.in.q1[myslot];
           ct = P.hin.tp[myslot].x;  // closest_so_far after part 1 of hitScene; the rest of that record stands unless a triangle wins
-          o = mk3(r0);
+          o = mk3(cam);
+          if (cam.w == 0.0f) o = mk3(P.in.q0[myslot]);  // (wave-uniform: step 0 picks a ray up with two gathers instead of three)
           d = mk3(r1);
           inv = rcp3_exact_il(d);
           negmask = (d.x < 0 ? 1u : 0u) | (d.y < 0 ? 2u : 0u) | (d.z < 0 ? 4u : 0u);
@@ -495,35 +500,46 @@ struct SlotState {
   float2 tp;
   uint32_t hitmat, slot;
 };
-DEV SlotState load_slot(const Paths& P, uint32_t slot, bool first) {
+DEV SlotState load_slot(const Paths& P, uint32_t slot, bool first, const RenderConst& rc) {
   SlotState st;
   st.slot = slot;
   st.hitmat = P.hin.mat[slot];
   st.q1 = P.in.q1[slot];
-  st.q0 = P.in.q0[slot];
-  if (first) st.q2 = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0));  // step 0: k_generate does not store what every path starts with
-  else st.q2 = P.in.q2[slot];
+  if (first) {  // step 0: k_generate does not store what every path starts with
+    const f3 co = cam_origin(rc);
+    st.q0 = make_float4(co.x, co.y, co.z, __uint_as_float(rng0_of(P)[slot]));
+    st.q2 = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0));
+  } else {
+    st.q0 = P.in.q0[slot];
+    st.q2 = P.in.q2[slot];
+  }
   st.tp = P.hin.tp[slot];
   return st;
 }
-// acc_radiance of a path as ray_color sees it; never-written entries stand for zero (P.touched, NUM_SAMPLES == 1)
-DEV float4 acc_load(const Paths& P, uint32_t pid) {
-  if (P.touched && !P.touched[pid]) return make_float4(0.0f, 0.0f, 0.0f, __int_as_float(0));
+// acc_radiance of a path as ray_color sees it; never-written entries stand for zero (P.touched, NUM_SAMPLES == 1).  Whether a path has
+// written its entry before travels WITH the path — bit kAccWritten of the bounce word in q2.w — so that k_shade never reads the flag
+// array: round 3 looked `touched[pid]` up and then `acc[pid]`, two dependent round trips to HBM in the middle of a group for every path
+// that ends or meets a light (one lane in four per step); now a path's first write is a blind store and only a path that has added
+// emission before (rare) loads its entry.  The flag array is still written (first store) — k_accumulate reads it.
+constexpr int kAccWritten = 0x40000000, kBounceMask = 0x3fffffff;
+DEV float4 acc_load(const Paths& P, uint32_t pid, bool written) {
+  if (P.touched && !written) return make_float4(0.0f, 0.0f, 0.0f, __int_as_float(0));
   return P.acc[pid];
 }
-DEV void acc_store(const Paths& P, uint32_t pid, float4 v) {
+DEV void acc_store(const Paths& P, uint32_t pid, float4 v, bool written) {
   P.acc[pid] = v;
-  if (P.touched) P.touched[pid] = 1;
+  if (P.touched && !written) P.touched[pid] = 1;
 }
 
 // The end of a path's only sample in progressive mode (NUM_SAMPLES == 1): acc_radiance += add; pixColor = (0 + acc_radiance) / 1.
 // `acc` is touched only when it changes: acc + (+-0) is acc bit for bit, and (0 + acc) / 1 is acc.
-DEV void end_sample_progressive(const Paths& P, uint32_t pid, f3 add) {
+DEV void end_sample_progressive(const Paths& P, uint32_t pid, f3 add, bool written) {
   const bool changes = !(add.x == 0.0f && add.y == 0.0f && add.z == 0.0f);  // NaN counts as a change
   if (changes) {
-    float4 A4 = acc_load(P, pid);
+    LT(LT_END_CHANGES);
+    float4 A4 = acc_load(P, pid, written);
     f3 fin = mk3(0, 0, 0) + (mk3(A4) + add);  // "/ NUM_SAMPLES" with NUM_SAMPLES == 1: x / 1.0f is x
-    acc_store(P, pid, make_float4(fin.x, fin.y, fin.z, __int_as_float(1)));
+    acc_store(P, pid, make_float4(fin.x, fin.y, fin.z, __int_as_float(1)), written);
   }  // else: (0 + acc) / 1 == acc, already in place — or never written, which k_accumulate reads as zero
 }
 
@@ -536,7 +552,8 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
   const f3 o = mk3(st.q0), d = mk3(st.q1);
   const float4 T4 = st.q2;
   f3 T = mk3(T4);
-  int bounce = __float_as_int(T4.w);
+  int bounce = __float_as_int(T4.w) & kBounceMask;
+  bool acc_written = (__float_as_int(T4.w) & kAccWritten) != 0;  // (progressive mode) this path has stored its acc_radiance before
   uint32_t rng = __float_as_uint(st.q0.w);
   const uint32_t prim = __float_as_uint(st.tp.y);
 
@@ -546,9 +563,11 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
   f3 no = o, nd = d;
 
   if ((prim >> 28) == K_NONE) {  // traceRay.wgsl:12-16
+    LT(LT_MISS);
     add = mk3(rc.bg[0], rc.bg[1], rc.bg[2]) * T;
     sample_done = true;
   } else {
+    LT(LT_HIT);
     int mat = (int)(st.hitmat & HITMAT_ID);
     Material m = load_material(S, mat);
     // the chunk is sorted by this class, so `bin` is wave-uniform almost everywhere
@@ -571,6 +590,7 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
         roulette = false;  // `continue` skips the Russian roulette
       } else {
         // get_random_on_quad(lights, hitRec.p) (importanceSampling.wgsl:78-81): u draw, then v draw
+        LT(LT_IS_LIGHT);
         float ru = rand2D(rng);
         f3 pu = ru * L.u;
         float rv = rand2D(rng);
@@ -603,6 +623,7 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
     }
     if (!sample_done) {
       if (roulette && bounce > 2) {  // traceRay.wgsl:71-79
+        LT(LT_RR);
         float p = ptm_max(T.x, ptm_max(T.y, T.z));
         if (rand2D(rng) > p) {
           sample_done = true;
@@ -621,21 +642,24 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
   ns.pid = pid;
   if (!sample_done) {
     if (changes) {
-      float4 A4 = acc_load(P, pid);
+      LT(LT_ACC_CONT);
+      float4 A4 = acc_load(P, pid, acc_written);
       f3 acc = mk3(A4) + add;
-      acc_store(P, pid, make_float4(acc.x, acc.y, acc.z, A4.w));
+      acc_store(P, pid, make_float4(acc.x, acc.y, acc.z, A4.w), acc_written);
+      acc_written = true;
     }
-    ns.o = no, ns.d = nd, ns.T = T, ns.bounce = bounce, ns.rng = rng;
+    ns.o = no, ns.d = nd, ns.T = T, ns.bounce = bounce | (acc_written ? kAccWritten : 0), ns.rng = rng;
     return true;
   }
 
   // pathTrace (shootRay.wgsl:5-49): pixColor += ray_color(ray); pixColor /= NUM_SAMPLES
+  LT(LT_END_SAMPLE);
   if (!MULTI) {
     if (drop_acc) {
       f3 fin = mk3(0, 0, 0) + add;  // (NUM_SAMPLES == 1: no division)
-      acc_store(P, pid, make_float4(fin.x, fin.y, fin.z, __int_as_float(1)));
+      acc_store(P, pid, make_float4(fin.x, fin.y, fin.z, __int_as_float(1)), acc_written);
     } else {
-      end_sample_progressive(P, pid, add);
+      end_sample_progressive(P, pid, add, acc_written);
     }
     return false;
   } else {
@@ -783,8 +807,12 @@ DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, St
         NewState ns;
         ns.o = ns.d = ns.T = mk3(0, 0, 0);
         ns.bounce = 0, ns.rng = 0, ns.pid = 0;
+#ifdef PTMI_NS_ZERO
+      ns.o = ns.d = ns.T = mk3(0, 0, 0);
+      ns.bounce = 0, ns.rng = 0, ns.pid = 0;
+#endif
         if (k < nvalid) {
-          const SlotState st = load_slot(P, base + s_sorted[k], first != 0);
+          const SlotState st = load_slot(P, base + s_sorted[k], first != 0, rc);
           const TriFetch tf = tri_fetch(S, P.uv, st.slot, __float_as_uint(st.tp.y));  // (issued ahead of the material's loads, consumed after them)
           survive = shade_one<IS, MULTI>(S, rc, P, st, tf, L, ns);
         }
@@ -799,8 +827,12 @@ DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, St
         NewState ns;
         ns.o = ns.d = ns.T = mk3(0, 0, 0);
         ns.bounce = 0, ns.rng = 0, ns.pid = 0;
+#ifdef PTMI_NS_ZERO
+      ns.o = ns.d = ns.T = mk3(0, 0, 0);
+      ns.bounce = 0, ns.rng = 0, ns.pid = 0;
+#endif
         if (j < m) {
-          const SlotState st = load_slot(P, base + j, first != 0);
+          const SlotState st = load_slot(P, base + j, first != 0, rc);
           valid = __float_as_uint(st.q1.w) != PID_HOLE;
           if (valid) {
             const TriFetch tf = tri_fetch(S, P.uv, st.slot, __float_as_uint(st.tp.y));  // (issued ahead of the material's loads, consumed after them)
@@ -830,7 +862,8 @@ DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, St
         rng = __float_as_uint(a0.w);
         prims_for_ray<COUNT>(S, mk3(a0), mk3(a1), rng, tp, hm, cn);  // (hit_volume draws from the path's stream: rng goes back into the state)
         if (kMissShortcut && !MULTI && hm == HITMAT_MISS) {  // traceRay.wgsl:12-16
-          end_sample_progressive(P, __float_as_uint(a1.w), mk3(rc.bg[0], rc.bg[1], rc.bg[2]) * mk3(s_q2[q]));
+          const float4 a2 = s_q2[q];
+          end_sample_progressive(P, __float_as_uint(a1.w), mk3(rc.bg[0], rc.bg[1], rc.bg[2]) * mk3(a2), (__float_as_int(a2.w) & kAccWritten) != 0);
           missed++;
         } else {
           keep = true;
@@ -933,6 +966,9 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
   constexpr uint32_t kR0Empty = 0xffffffffu, kR0Busy = 0xfffffffeu, kR0Full = 0xfffffffdu;
   __shared__ uint32_t s_region0;  // the waves' first regions: one claim per block (see shade_body)
   if (threadIdx.x == 0) s_region0 = kR0Empty;
+#ifdef PTMI_LANE_TALLY
+  if (threadIdx.x < kLaneTallies * 2) s_lane_tally[threadIdx.x] = 0u;
+#endif
   __syncthreads();
   const QuadL L = load_light(S);
   const int lane = lane_id();
@@ -952,11 +988,14 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
     float2 tp = make_float2(0.0f, 0.0f);
     uint32_t hm = 0u, rng = 0u;
     if ((uint32_t)lane < take) {
+      LT(LT_FLUSH);
       const float4 a0 = r0[q], a1 = r1[q];
       rng = __float_as_uint(a0.w);
       prims_for_ray<COUNT>(S, mk3(a0), mk3(a1), rng, tp, hm, cn);
       if (kMissShortcut && !MULTI && hm == HITMAT_MISS) {  // traceRay.wgsl:12-16 (see shade_body)
-        end_sample_progressive(P, __float_as_uint(a1.w), mk3(rc.bg[0], rc.bg[1], rc.bg[2]) * mk3(r2[q]));
+        LT(LT_MISS_SHORTCUT);
+        const float4 a2 = r2[q];
+        end_sample_progressive(P, __float_as_uint(a1.w), mk3(rc.bg[0], rc.bg[1], rc.bg[2]) * mk3(a2), (__float_as_int(a2.w) & kAccWritten) != 0);
       } else {
         keep = true;
       }
@@ -1011,6 +1050,7 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
         }
       }
       if (keep && (rank < n0 || b1 != 0xffffffffu)) {
+        LT(LT_KEEP);
         const uint32_t dst = (rank < n0) ? (b0 + rank) : (b1 + (rank - n0));
         float4 a0 = r0[q];
         a0.w = __uint_as_float(rng);
@@ -1030,13 +1070,15 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
     for (uint32_t j0 = wv * 64u; j0 < m; j0 += kBlock) {
       const uint32_t j = j0 + (uint32_t)lane;
       bool survive = false, valid = false;
-      NewState ns;
+      NewState ns;  // (zeroed although only the survivors' values are read: left undefined, the allocator needs 8 registers more — scratch at 80 VGPRs)
       ns.o = ns.d = ns.T = mk3(0, 0, 0);
       ns.bounce = 0, ns.rng = 0, ns.pid = 0;
       if (j < m) {
-        const SlotState st = load_slot(P, base + j, first != 0);
+        LT(LT_GROUP);
+        const SlotState st = load_slot(P, base + j, first != 0, rc);
         valid = __float_as_uint(st.q1.w) != PID_HOLE;
         if (valid) {
+          LT(LT_VALID);
           const TriFetch tf = tri_fetch(S, P.uv, st.slot, __float_as_uint(st.tp.y));  // (issued ahead of the material's loads, consumed after them)
           survive = shade_one<IS, MULTI>(S, rc, P, st, tf, L, ns);
         }
@@ -1044,6 +1086,7 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
       my_valid += (uint32_t)__popcll(__ballot(valid));
       const uint64_t mk = __ballot(survive);
       if (survive) {
+        LT(LT_STAGE);
         const uint32_t q = (head + cnt + lanes_below(mk)) & (kRing - 1u);
         r0[q] = make_float4(ns.o.x, ns.o.y, ns.o.z, __uint_as_float(ns.rng));
         r1[q] = make_float4(ns.d.x, ns.d.y, ns.d.z, __uint_as_float(ns.pid));
@@ -1057,6 +1100,9 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
   if (MULTI) my_missed = 0;  // (no path ends in the flush phase then)
   if (lane == 0 && my_missed + my_valid) atomicAdd(tally_line(totals, blockIdx.x), my_missed + my_valid);
   __syncthreads();  // the block's claim, if any wave made one, is in s_region0 now
+#ifdef PTMI_LANE_TALLY
+  if (threadIdx.x < kLaneTallies * 2 && s_lane_tally[threadIdx.x]) atomicAdd(&g_lane_tally[threadIdx.x], (unsigned long long)s_lane_tally[threadIdx.x]);
+#endif
   if (w_rend == 0u && s_region0 < kR0Full) {  // never needed a region: all of this wave's quarter of the block's claim becomes holes
     w_cur = s_region0 + wv * wregion;
     w_rend = w_cur + wregion;
@@ -1130,7 +1176,7 @@ __global__ __launch_bounds__(64) void k_tail(DevScene S, RenderConst rc, Paths P
         if (!alive && rank < take) {
           const uint32_t slot = gbase + pos + rank;
           if (slot < n) {
-            st = load_slot(P, slot, first != 0);
+            st = load_slot(P, slot, first != 0, rc);
             alive = __float_as_uint(st.q1.w) != PID_HOLE;
             uv = make_float2(0.0f, 0.0f);
           }
@@ -1182,7 +1228,7 @@ __global__ __launch_bounds__(64) void k_tail(DevScene S, RenderConst rc, Paths P
         }
       }
       // ---- ray_color's loop body (traceRay.wgsl:10-80) ----
-      NewState ns;
+      NewState ns;  // (zeroed although only the survivors' values are read: left undefined, the allocator needs 8 registers more — scratch at 80 VGPRs)
       ns.o = ns.d = ns.T = mk3(0, 0, 0);
       ns.bounce = 0, ns.rng = 0, ns.pid = 0;
       bool survive = false;
@@ -1198,7 +1244,7 @@ __global__ __launch_bounds__(64) void k_tail(DevScene S, RenderConst rc, Paths P
         float2 tp;
         prims_for_ray<COUNT>(S, ns.o, ns.d, rng, tp, hm, cn);
         if (kMissShortcut && !MULTI && hm == HITMAT_MISS) {  // traceRay.wgsl:12-16, as in k_shade's flush phase
-          end_sample_progressive(P, ns.pid, mk3(rc.bg[0], rc.bg[1], rc.bg[2]) * ns.T);
+          end_sample_progressive(P, ns.pid, mk3(rc.bg[0], rc.bg[1], rc.bg[2]) * ns.T, (ns.bounce & kAccWritten) != 0);
           tally++;
           alive = false;
         } else {
