@@ -53,8 +53,40 @@ FETCH_MULT = {"k_bvh": 1.0}  # bytes per FETCH_SIZE byte, calibrated per access 
 # its own record — k_bvh's fetch), measured by tools/gather_probe.hip (profiles/r03_gather_probe.json): 2.75-2.8 clocks per record per CU whether the table
 # sits in L1 (8 KB), in L2 (2 MB), is read lane-wise or quad-cooperatively, at 5 or 8 waves per SIMD; proportional to the lanes taking part
 # (profiles/r03_gather_probe2.json).  The same records from the Infinity Cache: 65 G/s, from HBM: 54 G/s.
-GATHER_PEAK_RECORDS_PER_S = 223.5e9
+GATHER_PEAK_RECORDS_PER_S = 223.5e9  # fallback; gather_peak() reads the probe's file
 GUIDE_MAX_CLOCK_GHZ = 2.4  # MI355X_MICROARCH.md "Max clock"
+N_CUS = 256
+
+
+def gather_peak():
+    """(records/s, clocks per record per CU, source): the per-lane 64-byte-record gather rate from the committed probe run
+    (profiles/r03_gather_probe.json, tools/gather_probe.hip), expressed at the guide's 2.4 GHz — the probe measures clocks per record."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r03_gather_probe.json")))
+        clk = [c["cycles_per_record_per_cu"] for c in d["cases"] if c.get("mode") == "lane" and c.get("table_kb", 1 << 30) <= 2048]
+        cpr = sorted(clk)[len(clk) // 2]
+        return N_CUS * GUIDE_MAX_CLOCK_GHZ * 1e9 / cpr, cpr, "profiles/r03_gather_probe.json: median of the lane-wise cases with tables of 8 KB .. 2 MB, i.e. L1- and L2-resident"
+    except Exception:
+        return GATHER_PEAK_RECORDS_PER_S, N_CUS * GUIDE_MAX_CLOCK_GHZ * 1e9 / GATHER_PEAK_RECORDS_PER_S, "built-in constant (profiles/r03_gather_probe.json unreadable)"
+
+
+def static_mix():
+    """Per kernel: what the cost model charges an instruction its counters cannot classify and an integer one — the kernel's own static mix
+    (profiles/r04_isa_histogram.json, tools/isa_histogram.py: moves / selects at 2 cycles, compares / min / max / f64 / division helpers at 4; integer add / logic
+    at 2, shifts / multiplies at 4).  Missing file or kernel: 4 and 4, the upper bound round 3 reported."""
+    mix = {}
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r04_isa_histogram.json")))["kernels"]
+        pick = {"k_shade": ("k_shade6<false, false>", "k_shade<true, true, false, false>"), "k_bvh": ("k_bvh2<false, true, false>",), "k_generate": ("k_generate<false>",),
+                "k_tail": ("k_tail<false, false, false, true>",), "k_accumulate": ("k_accumulate",)}
+        for k, names in pick.items():
+            for name in names:
+                e = next((v for n, v in d.items() if name in n), None)
+                if e and e.get("unclassified_avg_cycles"):
+                    mix.setdefault(k, {})[name] = (e["unclassified_avg_cycles"], e.get("int32_avg_cycles") or 4.0)
+    except Exception:
+        pass
+    return mix
 
 
 def alg_bytes(st):
@@ -131,13 +163,18 @@ PMC_PASSES = (
 # per SIMD): 2 cycles for f32 add/mul/fma (and mov, and/or/xor, integer add), 4 for min/max, compares, shifts, conversions, integer
 # multiplies, packed f32, f64 arithmetic and the v_div_* helpers, 8 for f32 transcendentals, 16 for v_rcp_f64.  The counters
 # can tell the 2-, 8- and 16-cycle classes apart; everything else is charged 4 (moves and integer adds too: an over-estimate).
-def issue_cycles(p, L, int_at=4.0):
-    """Issue cycles per launch.  int_at: what an integer VALU instruction (SQ_INSTS_VALU_INT32: add / logic at 2 cycles, shifts and multiplies at 4)
-    is charged — 4 gives the upper bound the line's `valu_busy_frac` is, 3 the middle of the class (`valu_busy_frac_int_at_3`)."""
+def issue_cycles(p, L, other_at=4.0, int_at=4.0):
+    """Issue cycles per launch of the kernel's own instruction mix: 2 per f32 add / mul / fma, 8 per f32 transcendental, 16 per v_rcp_f64, 4 per conversion
+    (counted classes), `int_at` per integer instruction (SQ_INSTS_VALU_INT32: add / logic issue in 2, shifts and multiplies in 4) and `other_at` per
+    instruction the counters cannot classify (moves / selects 2; compares, min / max, f64 arithmetic, division helpers 4).  4 and 4 = the upper bound;
+    the kernel's static mix (static_mix) = the model."""
     fast = (p.get("SQ_INSTS_VALU_ADD_F32", 0.0) + p.get("SQ_INSTS_VALU_MUL_F32", 0.0) + p.get("SQ_INSTS_VALU_FMA_F32", 0.0)) / max(p.get("launches_fetch", L), 1)
     n, t32, t64 = p["SQ_INSTS_VALU"] / L, p.get("SQ_INSTS_VALU_TRANS_F32", 0.0) / L, p.get("SQ_INSTS_VALU_TRANS_F64", 0.0) / L
     i32 = p.get("SQ_INSTS_VALU_INT32", 0.0) / max(p.get("launches_write", L), 1)
-    return 4.0 * n - 2.0 * min(fast, n) + 4.0 * t32 + 12.0 * t64 - (4.0 - int_at) * min(i32, n)
+    cvt = p.get("SQ_INSTS_VALU_CVT", 0.0) / max(p.get("launches_write", L), 1)
+    fast, i32, cvt = min(fast, n), min(i32, n), min(cvt, n)
+    other = max(0.0, n - fast - t32 - t64 - i32 - cvt)
+    return 2.0 * fast + 8.0 * t32 + 16.0 * t64 + 4.0 * cvt + int_at * i32 + other_at * other
 
 
 def pmc_child(args):
@@ -196,11 +233,12 @@ def pmc_passes(args, workload, log):
     return out, None
 
 
-def kernel_table(split, steps_in_split, pmc):
-    """Per-kernel figures: live ms per step (HIP events, uncounted kernels), and — from this run's PMC passes — VALU-busy
-    fraction, HBM bytes per launch, wait fraction, active lanes."""
+def kernel_table(split, steps_in_split, pmc, shade_variant=None):
+    """Per-kernel figures: live ms per step (HIP events, uncounted kernels), and — from this run's PMC passes — the VALU-issue fraction by the cost model
+    and by rocprof's own definition, HBM bytes per launch, wait fraction, active lanes.  No clamps: a model that says > 1 says so."""
     tab = {}
     total = sum(split[MS_KEY[k]] for k in KERNELS) or 1.0
+    mix = static_mix()
     for k in KERNELS:
         ms, n = split[MS_KEY[k]] / steps_in_split, max(split[LAUNCH_KEY[k]], 1) / steps_in_split
         e = {"ms_per_step": ms, "launches_per_step": n, "share_of_kernel_time": split[MS_KEY[k]] / total, "avg_launch_ms": ms / n if n else None}
@@ -209,25 +247,31 @@ def kernel_table(split, steps_in_split, pmc):
             L = p["launches_sq"]
             cyc = p["SQ_BUSY_CYCLES"] / 32.0 / L                      # kernel cycles per launch (the counter is summed over 8 XCDs x 4 SEs)
             clock = cyc / (p["pmc_ms_sq"] / L * 1e-3) if p["pmc_ms_sq"] else 0.0
-            busy = issue_cycles(p, L) / N_SIMD                        # issue cycles of this kernel's instruction mix, per SIMD and launch
-            busy4 = 4.0 * p["SQ_ACTIVE_INST_VALU"] / N_SIMD / L       # SQ_ACTIVE_INST_VALU counts quad-cycles, at least one per instruction
+            km = mix.get(k, {})
+            other_at, int_at = km.get(shade_variant) or (next(iter(km.values())) if km else (4.0, 4.0))
+            busy = issue_cycles(p, L, other_at, int_at) / N_SIMD      # issue cycles of this kernel's instruction mix, per SIMD and launch (static-mix model)
+            busy_ub = issue_cycles(p, L) / N_SIMD                     # the same with every unclassified / integer instruction at 4 cycles (upper bound)
+            busy4 = 4.0 * p["SQ_ACTIVE_INST_VALU"] / N_SIMD / L       # rocprof's VALUBusy numerator: SQ_ACTIVE_INST_VALU counts quad-cycles, at least one per instruction
             live_cyc = (ms / n * 1e-3) * clock if n and clock else cyc
             lanes = p["SQ_THREAD_CYCLES_VALU"] / (64.0 * p["SQ_ACTIVE_INST_VALU"]) if p["SQ_ACTIVE_INST_VALU"] else None
-            busy_raw = busy / live_cyc if live_cyc else None
+            frac = busy / live_cyc if live_cyc else None
+            ghz = clock / 1e9
             e.update({
                 "valu_instr_per_launch": p["SQ_INSTS_VALU"] / L,
-                "valu_busy_frac": min(1.0, busy_raw) if live_cyc else None,
-                "valu_busy_frac_unclamped_upper_bound": busy_raw,  # every instruction outside the f32 add/mul/fma, transcendental classes charged 4 cycles
-                "valu_busy_frac_int_at_3": (issue_cycles(p, L, 3.0) / N_SIMD / live_cyc) if live_cyc else None,
-                # the same busy cycles against the guide's 2.4 GHz instead of the clock the kernel actually ran at (DVFS loss shows up here)
-                "valu_busy_frac_at_2p4_ghz": (busy_raw * (clock / 1e9) / GUIDE_MAX_CLOCK_GHZ) if (live_cyc and clock) else None,
-                # issue slots that did useful work: busy fraction x active lanes per issued instruction
-                "lane_weighted_frac": (min(1.0, busy_raw) * lanes) if (live_cyc and lanes) else None,
-                "valu_busy_frac_4_cycles_per_instr": min(1.0, busy4 / live_cyc) if live_cyc else None,
-                "avg_cycles_per_valu_instr": issue_cycles(p, L) / (p["SQ_INSTS_VALU"] / L) if p["SQ_INSTS_VALU"] else None,
+                # THE fraction: busy issue cycles of the kernel's own mix / (1024 SIMDs x launch time x the guide's 2.4 GHz) — DVFS loss counts against the kernel
+                "valu_busy_frac_at_2p4_ghz": (frac * ghz / GUIDE_MAX_CLOCK_GHZ) if (frac is not None and clock) else None,
+                "valu_busy_frac_at_pass_clock": frac,
+                "valu_busy_frac_upper_bound_at_pass_clock": busy_ub / live_cyc if live_cyc else None,
+                # rocprof's own derived metrics for the same launches (its VALUBusy = 4 x SQ_ACTIVE_INST_VALU / SIMDs / cycles; VALUUtilization = active lanes):
+                # over-counts every 2-cycle instruction as a 4-cycle quad (tools/valu_busy_calib.sh, profiles/r04_valu_busy_calib.json)
+                "rocprof_valu_busy": busy4 / live_cyc if live_cyc else None,
+                "rocprof_valu_utilization": lanes,
+                "lane_weighted_frac_at_2p4_ghz": (frac * ghz / GUIDE_MAX_CLOCK_GHZ * lanes) if (frac is not None and clock and lanes) else None,
+                "avg_cycles_per_valu_instr": issue_cycles(p, L, other_at, int_at) / (p["SQ_INSTS_VALU"] / L) if p["SQ_INSTS_VALU"] else None,
+                "cost_model": {"unclassified_at": other_at, "int32_at": int_at},
                 "wave_wait_frac": p["SQ_WAIT_ANY"] / p["SQ_WAVE_CYCLES"] if p["SQ_WAVE_CYCLES"] else None,
                 "active_lane_frac": lanes,
-                "clock_ghz_in_pmc_pass": clock / 1e9,
+                "clock_ghz_in_pmc_pass": ghz,
                 "pmc_pass_avg_launch_ms": p["pmc_ms_sq"] / L,
             })
         if p and p.get("launches_fetch") and p.get("launches_write"):
@@ -239,57 +283,61 @@ def kernel_table(split, steps_in_split, pmc):
             mult = FETCH_MULT.get(k, 2.0)
             e["hbm_bytes_per_launch"] = mult * fb + wb
             e["hbm_bytes_per_launch_if_all_reads_were_streams"] = 2.0 * fb + wb
-            e["hbm_frac"] = min(1.0, e["hbm_bytes_per_launch"] / (ms / n * 1e-3) / (HBM_PEAK_GBS * 1e9)) if n and ms else None
+            e["hbm_frac"] = e["hbm_bytes_per_launch"] / (ms / n * 1e-3) / (HBM_PEAK_GBS * 1e9) if n and ms else None
         tab[k] = e
     return tab
 
 
 def roofline_of(tab, dom, timed_ms_per_launch, timed_launches, gather_records_per_launch=None):
-    """The contract's roofline object for the dominant kernel `dom`, in the unit of the bound it actually hits: the largest of
-    VALU issue (busy issue cycles of the kernel's own instruction mix), HBM (measured fabric bytes / 8 TB/s) and — for k_bvh — the L1 gather path
-    (64-byte records fetched per second / the rate tools/gather_probe.hip measures for that access pattern)."""
+    """The contract's roofline object for the dominant kernel `dom`, in the unit of the bound it comes closest to: VALU issue (busy issue cycles of
+    the kernel's own instruction mix against 1024 SIMDs at the guide's 2.4 GHz), HBM (measured fabric bytes / 8 TB/s) or — k_bvh — the L1 gather
+    path (64-byte records fetched per second / the rate tools/gather_probe.hip measures for that access pattern, at 2.4 GHz)."""
     e = tab[dom]
-    vf, hf = e.get("valu_busy_frac"), e.get("hbm_frac")
+    vf, hf = e.get("valu_busy_frac_at_2p4_ghz"), e.get("hbm_frac")
     r = {"kernel": dom, "avg_launch_ms": timed_ms_per_launch, "launches": timed_launches, "share_of_kernel_time": e["share_of_kernel_time"],
          "traffic": e.get("hbm_bytes_per_launch")}
     gf = None
+    gpeak, gcpr, gsrc = gather_peak()
     if dom == "k_bvh" and gather_records_per_launch and timed_ms_per_launch:
-        gf = gather_records_per_launch / (timed_ms_per_launch * 1e-3) / GATHER_PEAK_RECORDS_PER_S
+        gf = gather_records_per_launch / (timed_ms_per_launch * 1e-3) / gpeak
     if vf is None and hf is None and gf is None:
         r.update({"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None})
         return r
     # re-base the fractions on the launch time measured inside the timed region
     scale = (e["avg_launch_ms"] / timed_ms_per_launch) if (timed_ms_per_launch and e["avg_launch_ms"]) else 1.0
-    vf = min(1.0, vf * scale) if vf is not None else None
-    hf = min(1.0, hf * scale) if hf is not None else None
+    vf = vf * scale if vf is not None else None
+    hf = hf * scale if hf is not None else None
     best = max((x for x in (vf, hf, gf) if x is not None))
     if gf is not None and gf == best:
         gbs = gather_records_per_launch * 64.0 / (timed_ms_per_launch * 1e-3) / 1e9
-        r.update({"bound": "l1_gather", "achieved": gbs, "peak": GATHER_PEAK_RECORDS_PER_S * 64.0 / 1e9, "unit": "GB/s", "frac": gf,
+        r.update({"bound": "l1_gather", "achieved": gbs, "peak": gpeak * 64.0 / 1e9, "unit": "GB/s", "frac": min(1.0, gf), "frac_unclamped": gf,
                   "peak_definition": "64-byte BVH / triangle records fetched per lane (pair fetches = reference node visits below the root / 2, plus triangle tests; exact counters) "
-                                     "x 64 B / launch time, against the rate the 256 CUs' L1 / texture-addresser paths deliver such per-lane gathers at: 223.5 G records/s = 2.75-2.8 clocks "
-                                     "per record per CU, the same from L1, from L2, lane-wise or quad-cooperative, at 5 or 8 waves per SIMD (tools/gather_probe.hip, "
-                                     "profiles/r03_gather_probe.json).  Evidence that this, not HBM / latency / VALU, bounds k_bvh: its rate per node visit does not move with the scene's "
-                                     "size from 1 MB to 134 MB of digests (profiles/r03_size_sweep.txt) nor with occupancy from 18 to 26 waves per CU (DESIGN.md §4)"})
+                                     "x 64 B / launch time, against the rate the 256 CUs' L1 / texture-addresser paths deliver such per-lane gathers at: %.2f clocks per record per CU "
+                                     "at 2.4 GHz = %.1f G records/s (%s) — the same from L1, from L2, lane-wise or quad-cooperative, at 5 or 8 waves per SIMD.  The probe makes every lane "
+                                     "fetch a DISTINCT record; lanes that share a record (coherent rays, e.g. primary rays) are served by one fetch and counted per lane here, so the "
+                                     "fraction over-counts them and can pass 1 (clamped in `frac`, raw in `frac_unclamped`).  Evidence that this path, not HBM / latency / VALU, bounds "
+                                     "k_bvh: its rate per node visit does not move with the scene's size from 1 MB to 134 MB of digests (profiles/r03_size_sweep.txt) nor with "
+                                     "occupancy from 18 to 26 waves per CU (DESIGN.md §4)" % (gcpr, gpeak / 1e9, gsrc)})
     elif hf is not None and hf == best:
         gbs = e["hbm_bytes_per_launch"] / (timed_ms_per_launch * 1e-3) / 1e9
         r.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
     else:
         rate = e["valu_instr_per_launch"] / (timed_ms_per_launch * 1e-3) / 1e9
-        r.update({"bound": "valu_issue", "achieved": rate, "peak": rate / vf if vf else None, "unit": "G wave-instr/s", "frac": vf,
-                  "frac_is": "an UPPER bound of the VALU-busy fraction: instructions the counters cannot classify (moves, compares, min/max, conversions, integer) are charged 4 cycles although moves and "
-                             "integer adds issue in 2; see valu_busy_frac_int_at_3, frac_at_2p4_ghz and lane_weighted_frac next to it",
-                  "peak_definition": "the rate at which this kernel's own instruction mix issues when no SIMD is ever idle: 1024 SIMDs x clock / "
-                                     "(average issue cycles per wave64 instruction = %.2f: 2 for f32 add/mul/fma, 8 for f32 transcendentals, 16 for v_rcp_f64, 4 for "
-                                     "everything else — classes measured by tools/valu_peak.hip, profiles/valu_peak.json; class counts from this run's SQ_INSTS_VALU_* counters)"
-                                     % (e.get("avg_cycles_per_valu_instr") or 0.0)})
+        peak = N_SIMD * GUIDE_MAX_CLOCK_GHZ / e["avg_cycles_per_valu_instr"] if e.get("avg_cycles_per_valu_instr") else None
+        r.update({"bound": "valu_issue", "achieved": rate, "peak": peak, "unit": "G wave-instr/s", "frac": vf,
+                  "frac_is": "busy issue cycles of the kernel's own instruction mix / (1024 SIMDs x launch time x 2.4 GHz, the guide's clock): cycles per class measured by "
+                             "tools/valu_peak.hip (2 f32 add/mul/fma, 8 f32 transcendental, 16 v_rcp_f64, 4 conversions), integer and unclassified instructions at this "
+                             "kernel's static mix (cost_model; profiles/r04_isa_histogram.json).  Not clamped.  Next to it: the same at the clock the PMC pass ran at, the "
+                             "all-unclassified-at-4 upper bound, rocprof's own VALUBusy (counts every instruction as >= 4 cycles: a kernel of 2-cycle instructions reads "
+                             "2x too busy, profiles/r04_valu_busy_calib.json) and the lane-weighted fraction",
+                  "peak_definition": "1024 SIMDs x 2.4 GHz / (average issue cycles per wave64 instruction of this kernel = %.2f)" % (e.get("avg_cycles_per_valu_instr") or 0.0)})
     if max(vf or 0.0, hf or 0.0, gf or 0.0) < 0.5:
         r["bound_note"] = "no resource is busy half the time: the kernel waits on memory latency (wave_wait_frac %.2f)" % (e.get("wave_wait_frac") or 0.0)
-    r["valu_busy_frac"], r["hbm_frac"], r["l1_gather_frac"] = vf, hf, gf
-    # the honest distance to the ceiling (VERDICT round 2): the same busy cycles at the guide's 2.4 GHz, with integer instructions at 3 cycles, and weighted by active lanes
-    for k in ("valu_busy_frac_at_2p4_ghz", "valu_busy_frac_int_at_3", "lane_weighted_frac", "valu_busy_frac_unclamped_upper_bound", "clock_ghz_in_pmc_pass"):
+    r["valu_busy_frac_at_2p4_ghz"], r["hbm_frac"], r["l1_gather_frac"] = vf, hf, gf
+    for k in ("valu_busy_frac_at_pass_clock", "valu_busy_frac_upper_bound_at_pass_clock", "rocprof_valu_busy", "rocprof_valu_utilization", "lane_weighted_frac_at_2p4_ghz",
+              "clock_ghz_in_pmc_pass", "cost_model"):
         if e.get(k) is not None:
-            r[{"valu_busy_frac_at_2p4_ghz": "frac_at_2p4_ghz"}.get(k, k)] = e[k] * (scale if k not in ("clock_ghz_in_pmc_pass",) else 1.0)
+            r[k] = e[k] * scale if k.startswith(("valu_busy", "rocprof_valu_busy", "lane_weighted")) else e[k]
     return r
 
 
@@ -311,13 +359,16 @@ def measure(pkg, torch, pdist, ctx, wl, spp, steps, warmup, reduce_fn):
     """reduce_fn: the step's collective (None on one GPU) — torch.distributed's reduce of the bound framebuffer tensor when the driver starts one
     process per GPU, ptmi_reduce_framebuffer (ncclReduce inside the library) when one process drives all GPUs."""
     view = wl["view"]
+    coll = [0.0]  # seconds this rank spent in the step's collective (the wait for the slowest rank included)
 
     def step():
         ctx.clear()
         ctx.render(view, 1, spp)
         ctx.synchronize()
         if reduce_fn is not None:
+            t = time.perf_counter()
             reduce_fn()
+            coll[0] += time.perf_counter() - t
 
     for _ in range(warmup):
         step()
@@ -335,6 +386,7 @@ def measure(pkg, torch, pdist, ctx, wl, spp, steps, warmup, reduce_fn):
     if torch is not None:
         torch.cuda.synchronize()
     pdist.barrier()
+    coll[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -343,6 +395,7 @@ def measure(pkg, torch, pdist, ctx, wl, spp, steps, warmup, reduce_fn):
         torch.cuda.synchronize()
     pdist.barrier()
     dt = time.perf_counter() - t0
+    coll_ms = coll[0] / max(steps, 1) * 1e3
     st = ctx.stats()
     ctx.set_timing(0)
     # exact work counters of one step (counted variants of the same kernels, untimed)
@@ -353,7 +406,32 @@ def measure(pkg, torch, pdist, ctx, wl, spp, steps, warmup, reduce_fn):
     cst = ctx.stats()
     ctx.set_counters(False)
     assert cst["rays"] * steps == st["rays"], "ray count differs between the counted and the timed pass"
-    return {"dt": dt, "st": st, "split": split, "cst": cst, "dom": dom}
+    return {"dt": dt, "st": st, "split": split, "cst": cst, "dom": dom, "collective_ms_per_step": coll_ms}
+
+
+def measure_short(torch, pdist, ctx, wl, spp, steps, reduce_fn):
+    """The other scaling mode's figure for the same line (N > 1): a few steps, no per-kernel split, no counted pass."""
+    def step():
+        ctx.clear()
+        ctx.render(wl["view"], 1, spp)
+        ctx.synchronize()
+        if reduce_fn is not None:
+            reduce_fn()
+
+    step()
+    ctx.synchronize()
+    ctx.reset_stats()
+    if torch is not None:
+        torch.cuda.synchronize()
+    pdist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.synchronize()
+    if torch is not None:
+        torch.cuda.synchronize()
+    pdist.barrier()
+    return time.perf_counter() - t0, ctx.stats()
 
 
 def cpu_baseline(pkg, wl, spp, args):
@@ -416,7 +494,11 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=0, help="progressive frames per step (0 = the config's: 64 for c2, 256 for c3, 512 for c4, 1024 for c5); per GPU with --scaling weak, in total with strong")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: weak = spp x N (fixed rays per GPU), strong = fixed total spp (fixed total rays)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: weak = spp x N (fixed rays per GPU), strong = fixed total spp (fixed total rays); "
+                                                                                 "the line carries the other mode's figure too (config.other_scaling)")
+    ap.add_argument("--collective", default="reduce", choices=["reduce", "gather"],
+                    help="one process per GPU: reduce = sum-reduce of the full accumulation buffers to rank 0 (north_star's wording); gather = every rank sends the tiles "
+                         "it owns, 1/N of the bytes, no arithmetic (SURVEY.md 8e's equivalent)")
     ap.add_argument("--stack-size", type=int, default=0)
     ap.add_argument("--tris", type=int, default=0, help="experiments: tessellate the procedural mesh of c3/c4/c5 to this many triangles (0 = the configuration's count)")
     ap.add_argument("--bounces", type=int, default=8)
@@ -490,16 +572,28 @@ def main():
             ctx.bind_framebuffer(fb_t.data_ptr(), fb_t.numel() * 4)
             ctx.set_shard(rank, world, pdist.TILE_PIXELS)
 
+            def collective(t):
+                if args.collective == "gather":
+                    pdist.gather_tiles(t, pdist.TILE_PIXELS, 0)
+                else:
+                    pdist.reduce_framebuffer(t, 0)
+
             def reduce_fn():
                 if args.rehearse_gloo:
                     host = fb_t.cpu()
-                    pdist.reduce_framebuffer(host, 0)
+                    collective(host)
                     fb_t.copy_(host)
                 else:
-                    pdist.reduce_framebuffer(fb_t, 0)
-                torch.cuda.synchronize()  # the reduce runs on torch's stream; the next clear runs on the context's
+                    collective(fb_t)
+                torch.cuda.synchronize()  # the collective runs on torch's stream; the next clear runs on the context's
 
         m = measure(pkg, torch, pdist, ctx, wl, spp, steps, warmup, reduce_fn)
+        if world > 1:  # the other scaling mode, briefly: strong next to the default weak (fixed total spp: the reading of BASELINE configs[3] / [4]), or the reverse
+            spp_o = per if args.scaling == "weak" else per * world
+            dt_o, st_o = measure_short(torch, pdist, ctx, wl, spp_o, max(1, min(steps, 5)), reduce_fn)
+            m["other"] = {"scaling": "strong" if args.scaling == "weak" else "weak", "spp": spp_o, "steps": max(1, min(steps, 5)), "dt": dt_o, "rays": st_o["rays"]}
+        m["reduce_info"] = ctx.reduce_info() if inlib else None
+        m["reduce_mode"] = ctx.stats().get("reduce_mode") if inlib else None
         return wl, ctx, spp, per, m
 
     wl, ctx, spp, per, m = run_workload(args.workload, args.steps, args.warmup, args.spp)
@@ -507,18 +601,35 @@ def main():
     dt_max = pdist.all_reduce_scalar(m["dt"], "max")
     rays_all = pdist.all_reduce_scalar(st["rays"], "sum")
     paths_all = pdist.all_reduce_scalar(st["paths"], "sum")
+    o_rays = o_dt = None
+    if world > 1:  # (collectives: every rank takes part)
+        o_rays, o_dt = pdist.all_reduce_scalar(m["other"]["rays"], "sum"), pdist.all_reduce_scalar(m["other"]["dt"], "max")
 
     def describe(wl, spp, per, m, steps, rays, paths, dt, pm):
         """value / roofline / kernel table of one measured workload."""
         st, cst, dom = m["st"], m["cst"], m["dom"]
-        tab = kernel_table(m["split"], 1, pm)
+        tab = kernel_table(m["split"], 1, pm, "k_shade<true, true, false, false>" if wl["extra"].get("importance_sampling") else "k_shade6<false, false>")
         n_dom = max(st[LAUNCH_KEY[dom]], 1)
         bvh_launches = max(m["split"][LAUNCH_KEY["k_bvh"]], 1)
         gather = (cst["bvh_node_visits"] / 2.0 + cst["tri_tests"]) / bvh_launches  # 64-byte records k_bvh fetches per launch (pair records + triangle records)
         roof = roofline_of(tab, dom, st[MS_KEY[dom]] / n_dom, n_dom, gather)
         if tab["k_bvh"]["ms_per_step"] > 0:
-            tab["k_bvh"]["l1_gather_frac"] = gather * bvh_launches / (tab["k_bvh"]["ms_per_step"] * 1e-3) / GATHER_PEAK_RECORDS_PER_S
+            tab["k_bvh"]["l1_gather_frac"] = gather * bvh_launches / (tab["k_bvh"]["ms_per_step"] * 1e-3) / gather_peak()[0]  # (not clamped: coherent lanes sharing a record count per lane)
             tab["k_bvh"]["records_per_launch"] = gather
+        # What SURVEY §8d's yardstick calls waste: HBM bytes the step moves beyond what the reference's megakernel must move — its framebuffer read-modify-write
+        # once per frame (32 B per pixel and frame) and the scene once.  The wavefront design pays the rest as path state crossing HBM between kernels.
+        if all(tab[k].get("hbm_bytes_per_launch") is not None for k in KERNELS):
+            step_bytes = sum(tab[k]["hbm_bytes_per_launch"] * tab[k]["launches_per_step"] for k in KERNELS)
+            scene_bytes = sum(np.asarray(wl["buffers"][k]).nbytes for k in ("spheres", "quads", "triangles", "meshes", "transforms", "materials", "bvh"))
+            compulsory = 32.0 * wl["W"] * wl["H"] * spp / max(world, 1) + scene_bytes
+            roof["step_hbm_bytes"] = step_bytes
+            roof["compulsory_bytes"] = compulsory
+            roof["state_traffic_bytes"] = step_bytes - compulsory
+            roof["state_over_compulsory"] = (step_bytes - compulsory) / compulsory if compulsory else None
+            roof["step_hbm_frac"] = step_bytes / (dt / steps) / (HBM_PEAK_GBS * 1e9)
+            roof["traffic_note"] = ("step_hbm_bytes = measured fabric bytes of all kernels of one step (this run's FETCH_SIZE / WRITE_SIZE passes); compulsory_bytes = the reference "
+                                    "megakernel's own HBM need (framebuffer RMW per pixel and frame + the scene once); the difference is wavefront path state (queues, hit "
+                                    "records, per-path radiance) that the reference never moves — waste by SURVEY §8d's yardstick, the price of compaction and lane refill")
         hit_scene_gbs = alg_bytes(cst) / (m["split"]["render_ms"] / 1e3) / 1e9 if m["split"]["render_ms"] > 0 else None
         roof["algorithmic_hit_scene_gbs_informational"] = hit_scene_gbs  # SURVEY §8d reference-layout bytes / render time: cache-oblivious, NOT a fraction of HBM peak
         roof["work_per_ray"] = {k: cst[k] / max(cst["rays"], 1) for k in ("node_visits", "bvh_node_visits", "tri_tests", "quad_tests", "sphere_tests", "mat_fetches")}
@@ -526,7 +637,9 @@ def main():
         return {
             "value": rays / dt / 1e6, "ms_per_step": dt / steps * 1e3, "rays_per_step": rays / steps, "mpaths_per_s": paths / dt / 1e6,
             "workload": "%s, %dx%d, %d spp%s, %d bounces, stack_size %d%s" % (
-                wl["label"], wl["W"], wl["H"], spp, (" (%d per GPU x %d)" % (per, world) if world > 1 and args.scaling == "weak" else ""), wl["bounces"], wl["stack"],
+                wl["label"], wl["W"], wl["H"], spp,
+                ("" if world == 1 else " (weak scaling: %d per GPU x %d GPUs, every GPU traces 1/%d of the pixels for all of them)" % (per, world, world) if args.scaling == "weak"
+                 else " in total (strong scaling: every one of the %d GPUs traces 1/%d of the pixels, %d spp each)" % (world, world, spp)), wl["bounces"], wl["stack"],
                 ", SAH BVH (opt-in)" if args.bvh == "sah" else ""),
             "roofline": roof,
         }
@@ -551,12 +664,20 @@ def main():
                 "workload": d["workload"],
                 "rays_per_step": d["rays_per_step"],
                 "mpaths_per_s": d["mpaths_per_s"],
-                "parallelism": ("ptmi_create_multi x%d (one process, one context; devices %s) + 1 ncclReduce inside the library%s" % (
-                    world, ",".join(map(str, devices)), "" if len(set(devices)) == len(devices) else "; REHEARSAL: shards share a GPU, summed by a kernel") if inlib
-                    else ("pixel tiles x%d (one process per GPU) + 1 RCCL reduce (torch.distributed)" % world) if world > 1 else "1 GPU"),
+                "parallelism": ("ptmi_create_multi x%d (one process, one context; devices %s); the step's collective inside the library: %s%s" % (
+                    world, ",".join(map(str, devices)), m["reduce_info"], "" if len(set(devices)) == len(devices) else "; REHEARSAL: shards share a GPU") if inlib
+                    else ("pixel tiles x%d (one process per GPU) + 1 RCCL %s per step (torch.distributed%s)" % (
+                        world, "reduce of the full accumulation buffers" if args.collective == "reduce" else "gather of every rank's own tiles", "; REHEARSAL over gloo on host copies" if args.rehearse_gloo else ""))
+                    if world > 1 else "1 GPU"),
             },
             "roofline": d["roofline"],
         }
+        if world > 1:
+            out["config"]["collective_ms_per_step"] = m["collective_ms_per_step"]  # rank 0's wall time inside the collective, its wait for the slowest rank included
+            out["config"]["collective_bytes_into_root"] = (world - 1) * wl["W"] * wl["H"] * 16 // (1 if (inlib or args.collective == "reduce") else world)
+            o = m["other"]
+            out["config"]["other_scaling"] = {"scaling": o["scaling"], "spp_total": o["spp"], "steps": o["steps"], "value": o_rays / o_dt / 1e6, "unit": "Mrays/s",
+                                              "ms_per_step": o_dt / o["steps"] * 1e3, "note": "informational: the same ranks and collective in the other scaling mode; `value` above is --scaling %s" % args.scaling}
         if args.workload in pmc_note:
             out["roofline"]["pmc_note"] = pmc_note[args.workload]
         elif pmc.get(args.workload):

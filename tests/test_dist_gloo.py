@@ -39,8 +39,12 @@ def _worker(rank, world, port, outdir):
     mask = pdist.owned_pixel_mask(W * H, rank, world, TILE)
     assert np.array_equal(fb.reshape(-1, 4)[:, 3] == 1.0, mask)  # touched exactly the owned pixels
     t = torch.from_numpy(fb.reshape(-1).copy())
+    t2 = t.clone()
     pdist.barrier()
     pdist.reduce_framebuffer(t, 0)
+    pdist.gather_tiles(t2, TILE, 0)  # the same collective from 1/N of the bytes: rank 0 must end up with the very same image
+    if rank == 0:
+        assert torch.equal(t.view(torch.int32), t2.view(torch.int32))
     rays = pdist.all_reduce_scalar(st["rays"], "sum")
     slowest = pdist.all_reduce_scalar(float(rank + 1), "max")
     assert slowest == float(world)

@@ -1,5 +1,7 @@
-"""Multi-GPU plumbing: one process per GPU, pixel-tile sharding, ONE sum-reduce of the accumulation
-buffer to rank 0 (RCCL over xGMI through torch.distributed's "nccl" backend; "gloo" on CPU for tests).
+"""Multi-GPU plumbing: one process per GPU, pixel-tile sharding, ONE collective per render — the sum-reduce of the
+accumulation buffers to rank 0 (reduce_framebuffer: north_star's wording, bench.py's default) or the gather of every
+rank's own tiles (gather_tiles: the same image from 1/N of the bytes) — RCCL over xGMI through torch.distributed's
+"nccl" backend; "gloo" on CPU for tests.
 
 The image is embarrassingly parallel per pixel (main.wgsl:4,16: a pixel depends only on its index, the
 frame number, the scene and the view), so ranks never exchange anything while rendering.  Each rank
@@ -48,6 +50,49 @@ def reduce_framebuffer(fb_tensor, dst=0):
 
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.reduce(fb_tensor, dst=dst, op=dist.ReduceOp.SUM)
+    return fb_tensor
+
+
+_tile_index_cache = {}
+
+
+def owned_pixel_index(npix, rank, world, tile, device):
+    """int64 tensor of the pixels `rank` owns, in image order (cached per shape and device)."""
+    import torch
+
+    key = (npix, rank, world, tile, str(device))
+    if key not in _tile_index_cache:
+        p = torch.arange(npix, dtype=torch.int64, device=device)
+        _tile_index_cache[key] = p[((p // tile) % world) == rank].contiguous()
+    return _tile_index_cache[key]
+
+
+def gather_tiles(fb_tensor, tile=TILE_PIXELS, dst=0):
+    """The same collective with 1/N of the bytes ("or equivalently an all-gather on a tile-major layout"): every pixel is non-zero on
+    exactly one rank, so instead of summing N full framebuffers each rank packs the tiles it owns (npix/N pixels) and rank `dst` gathers the packs and
+    puts them in place — no arithmetic at all, the N-GPU image is the 1-GPU image bit for bit.  torch.distributed.gather = grouped send / recv over
+    RCCL (xGMI point to point: the N-1 packs arrive over N-1 links at once)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return fb_tensor
+    rank, world = dist.get_rank(), dist.get_world_size()
+    fb = fb_tensor.view(-1, 4)
+    npix = fb.shape[0]
+    n_max = max(int(owned_pixel_index(npix, r, world, tile, fb.device).numel()) for r in range(world))  # packs are padded to one length
+    mine = owned_pixel_index(npix, rank, world, tile, fb.device)
+    pack = torch.zeros((n_max, 4), dtype=fb.dtype, device=fb.device)
+    pack[: mine.numel()] = fb[mine]
+    if rank == dst:
+        parts = [torch.empty_like(pack) for _ in range(world)]
+        dist.gather(pack, parts, dst=dst)
+        for r in range(world):
+            if r != dst:
+                idx = owned_pixel_index(npix, r, world, tile, fb.device)
+                fb[idx] = parts[r][: idx.numel()]
+    else:
+        dist.gather(pack, None, dst=dst)
     return fb_tensor
 
 
