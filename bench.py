@@ -483,6 +483,18 @@ def js_bvh_build(native):
         os.remove(f.name)
 
 
+def obj_parse_times(n_tris):
+    """the native OBJ parser (1 and 16 host threads) against the reference's reader in JavaScript under Node on a generated
+    file of the workload's triangle count (tools/obj_parse_bench.py: nothing is fetched, the text is written to /tmp).  Host work only."""
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "obj_parse_bench.py"), str(n_tris)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        if r.returncode != 0:
+            return {"error": r.stderr[-300:]}
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        return {"error": str(e)[:200]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -745,6 +757,7 @@ def main():
                                                "note": "ptmi_upload x7 (triangles in mesh order, no BVH) + ptmi_build_scene_bvh + ptmi_prepare: the whole scene set-up after the host's packing"}
             if args.cpu_seconds > 0:
                 wl3["setup"]["bvh_build_js_single_thread"] = js_bvh_build(wl3["native"])
+                wl3["setup"]["obj_parse"] = obj_parse_times(wl3["buffers"]["triangles"].size // 24)
             d3["setup_ms"] = wl3["setup"]
             out["configs"] = [d3]
             # top-level vs_baseline stays null: BASELINE.md publishes no Mrays/s for configs[1]; the dragon ratio belongs to the configs[2] run above

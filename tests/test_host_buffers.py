@@ -178,6 +178,37 @@ def test_obj_grammar_quirks_python_vs_native(pkg):
     assert np.isnan(v).sum() >= 3                        # index 9 and 0 do not exist
 
 
+def test_native_obj_parser_is_thread_count_invariant(pkg, monkeypatch):
+    """ptmi_obj_parse cuts the text at line ends into one run per host thread (>= 1 MB each) and de-indexes in parallel: the same bytes with 1, 3
+    or 8 threads, on a file whose cut points fall next to the awkward lines (CRLF, blank, tab-indented, junk tokens, no newline at the end), and
+    the bytes of the Python mirror of the reference's reader (lib/primitives/objReader.js:10-68)."""
+    from webgpu_path_tracer_amd.host import ObjReader
+
+    rng = np.random.default_rng(11)
+    nv = 30000
+    rows = ["v %.6f %.6f %.6f" % tuple(r) for r in rng.uniform(-1, 1, (nv, 3))]
+    norms = ["vn %.4f %.4f %.4f" % tuple(r) for r in rng.uniform(-1, 1, (nv, 3))]
+    idx = rng.integers(1, nv + 1, (90000, 3))
+    faces = ["f %d/1/%d %d/1/%d %d/1/%d" % (a, a, b, b, c, c) for a, b, c in idx]
+    odd = ["", "# comment", "\tvn 1 0 0  \r", "v  1 2 3", "f 1//2 999999/9/9 0/0/0", "v 0x10 Infinity abc", "vt 0 0", "g grp"]
+    lines = []
+    for k, l in enumerate(rows + norms + faces):
+        lines.append(l)
+        if k % 997 == 0:
+            lines.append(odd[(k // 997) % len(odd)])
+    text = "\n".join(lines)  # (no newline at the end)
+    assert len(text) > 5 << 20
+    nat = pkg.ptmi.NativeHost()
+    out = {}
+    for t in ("1", "3", "8"):
+        monkeypatch.setenv("PTMI_BUILD_THREADS", t)
+        out[t] = nat.parse_obj(text)
+    want = ObjReader.parse(text)
+    for t, r in out.items():
+        for k in ("vertices", "normals"):
+            assert r[k].size == want[k].size and np.array_equal(r[k].view(np.uint32), want[k].view(np.uint32)), (t, k)
+
+
 @needs_assets
 def test_native_obj_parser_matches_python_on_reference_meshes(pkg):
     import glob

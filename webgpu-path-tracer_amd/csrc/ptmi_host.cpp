@@ -6,6 +6,7 @@
 // to f32 on the final store like `new Float32Array(...)` (lib/scene.js:304).  Output is byte-identical
 // to the reference's for the same boxes (tests/test_host_buffers.py checks it against goldens).
 #include <algorithm>
+#include <charconv>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -356,11 +357,10 @@ namespace {
 bool js_space(unsigned char ch) { return ch == ' ' || ch == '\t' || ch == '\r' || ch == '\n' || ch == '\v' || ch == '\f'; }
 
 // JavaScript Number(token) for the tokens an OBJ line can produce: "" -> 0, decimal literals with optional sign /
-// fraction / exponent, [+-]Infinity, 0x / 0o / 0b integers; anything else -> NaN.
-double js_number(const char* b, const char* e) {
-  while (b < e && js_space((unsigned char)*b)) b++;
-  while (e > b && js_space((unsigned char)e[-1])) e--;
-  if (b == e) return 0.0;
+// fraction / exponent, [+-]Infinity, 0x / 0o / 0b integers; anything else -> NaN.  Decimal literals — every token of a
+// well-formed file — are checked against the strict grammar in place and converted by std::from_chars (correctly rounded like
+// V8's, no locale, no copy); the rare other forms take the slow path.
+double js_number_slow(const char* b, const char* e) {
   std::string t(b, e);
   const char* p = t.c_str();
   bool neg = false;
@@ -392,6 +392,33 @@ double js_number(const char* b, const char* e) {
   if (*r != 0) return NAN;
   return strtod(p, nullptr);
 }
+double js_number(const char* b, const char* e) {
+  while (b < e && js_space((unsigned char)*b)) b++;
+  while (e > b && js_space((unsigned char)e[-1])) e--;
+  if (b == e) return 0.0;
+  const char* q = b;
+  if (*q == '+' || *q == '-') q++;
+  const char* r = q;
+  int digits = 0;
+  while (r < e && *r >= '0' && *r <= '9') r++, digits++;
+  if (r < e && *r == '.') {
+    r++;
+    while (r < e && *r >= '0' && *r <= '9') r++, digits++;
+  }
+  if (digits == 0) return js_number_slow(b, e);  // Infinity, or not a number
+  if (r < e && (*r == 'e' || *r == 'E')) {
+    const char* x = r + 1;
+    if (x < e && (*x == '+' || *x == '-')) x++;
+    if (!(x < e && *x >= '0' && *x <= '9')) return js_number_slow(b, e);
+    while (x < e && *x >= '0' && *x <= '9') x++;
+    r = x;
+  }
+  if (r != e) return js_number_slow(b, e);  // 0x.., trailing garbage
+  double v = 0.0;
+  const auto res = std::from_chars(*b == '+' ? b + 1 : b, e, v, std::chars_format::general);
+  if (res.ec != std::errc() || res.ptr != e) return js_number_slow(b, e);  // (out of range: strtod's +-inf / 0, JavaScript's answer too)
+  return v;
+}
 
 struct ObjRows {
   std::vector<double> data;      // all numbers of all rows, concatenated
@@ -417,61 +444,143 @@ struct ObjRows {
 
 extern "C" void ptmi_free(void* p) { free(p); }
 
+// One run of whole lines [p, end) of the file: the rows and index tokens it contains, in order.
+struct ObjChunk {
+  ObjRows V, N;
+  std::vector<double> vidx, nidx;  // doubles: an index token may be NaN
+};
+static void obj_parse_lines(const char* p, const char* end, ObjChunk& c) {
+  // One allocation per array instead of a dozen doublings (each a fresh mapping, a copy and page faults under the process's one mm lock — with several
+  // threads at it the parser spent more time in the kernel than parsing): a number takes >= 2 characters of the text, rows >= 8; untouched pages cost nothing.
+  const size_t len = (size_t)(end - p);
+  c.V.data.reserve(len / 6), c.N.data.reserve(len / 6), c.V.offset.reserve(len / 16 + 2), c.N.offset.reserve(len / 16 + 2);
+  c.vidx.reserve(len / 6), c.nidx.reserve(len / 6);
+  while (p <= end) {
+    const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+    const char* le = nl ? nl : end;
+    const char *b = p, *e = le;  // line.trim()
+    while (b < e && js_space((unsigned char)*b)) b++;
+    while (e > b && js_space((unsigned char)e[-1])) e--;
+    if (b < e && *b != '#') {
+      if (e - b >= 2 && b[0] == 'v' && b[1] == ' ') {
+        c.V.add_row_split_on_space(b, e);
+      } else if (e - b >= 2 && b[0] == 'f' && b[1] == ' ') {  // split(/[\s/]+/).slice(1); i % 3 == 0 -> vertex, == 2 -> normal
+        const char* q = b;
+        int tok = -1;  // token 0 is "f"
+        while (q < e) {
+          const char* t0 = q;
+          while (q < e && !js_space((unsigned char)*q) && *q != '/') q++;
+          if (tok >= 0) {
+            if (tok % 3 == 0) c.vidx.push_back(js_number(t0, q) - 1);
+            else if (tok % 3 == 2) c.nidx.push_back(js_number(t0, q) - 1);
+          }
+          tok++;
+          while (q < e && (js_space((unsigned char)*q) || *q == '/')) q++;
+        }
+      } else if (e - b >= 3 && b[0] == 'v' && b[1] == 'n' && b[2] == ' ') {
+        c.N.add_row_split_on_space(b, e);
+      }
+    }
+    if (!nl) break;
+    p = nl + 1;
+  }
+}
+
+static unsigned host_threads(size_t work_items, size_t per_thread) {
+  unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  if (const char* e = getenv("PTMI_BUILD_THREADS")) hw = (unsigned)std::max(1, atoi(e));
+  return (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(hw, 32u), work_items / std::max<size_t>(per_thread, 1) + 1));
+}
+
+// The file is cut at line ends into one run of lines per host thread (lines are independent: indices are absolute row numbers), the runs'
+// rows and index tokens are concatenated in file order, and the de-indexing is parallel over the index tokens.  PTMI_BUILD_THREADS limits
+// the threads (1 = the sequential parser); the output is the same bytes whatever the number.
 extern "C" int ptmi_obj_parse(const char* text, size_t len, float** vertices_out, size_t* n_vertices, float** normals_out, size_t* n_normals) {
   if (!text || !vertices_out || !n_vertices || !normals_out || !n_normals) return PTMI_ERR_INVALID_ARG;
   *vertices_out = *normals_out = nullptr;
   *n_vertices = *n_normals = 0;
-  ObjRows V, N;
-  std::vector<double> vidx, nidx;  // doubles: an index token may be NaN
   try {
-    const char* p = text;
     const char* end = text + len;
-    while (p <= end) {
-      const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
-      const char* le = nl ? nl : end;
-      const char *b = p, *e = le;  // line.trim()
-      while (b < e && js_space((unsigned char)*b)) b++;
-      while (e > b && js_space((unsigned char)e[-1])) e--;
-      if (b < e && *b != '#') {
-        if (e - b >= 2 && b[0] == 'v' && b[1] == ' ') {
-          V.add_row_split_on_space(b, e);
-        } else if (e - b >= 2 && b[0] == 'f' && b[1] == ' ') {  // split(/[\s/]+/).slice(1); i % 3 == 0 -> vertex, == 2 -> normal
-          const char* q = b;
-          int tok = -1;  // token 0 is "f"
-          while (q < e) {
-            const char* t0 = q;
-            while (q < e && !js_space((unsigned char)*q) && *q != '/') q++;
-            if (tok >= 0) {
-              if (tok % 3 == 0) vidx.push_back(js_number(t0, q) - 1);
-              else if (tok % 3 == 2) nidx.push_back(js_number(t0, q) - 1);
-            }
-            tok++;
-            while (q < e && (js_space((unsigned char)*q) || *q == '/')) q++;
-          }
-        } else if (e - b >= 3 && b[0] == 'v' && b[1] == 'n' && b[2] == ' ') {
-          N.add_row_split_on_space(b, e);
+    const unsigned nt = host_threads(len, (size_t)1 << 20);
+    std::vector<const char*> cut(nt + 1, end);
+    cut[0] = text;
+    for (unsigned k = 1; k < nt; k++) {  // the first line start at or after k/nt of the file
+      const char* want = text + (len / nt) * k;
+      if (want < cut[k - 1]) want = cut[k - 1];
+      const char* nl = want < end ? (const char*)memchr(want, '\n', (size_t)(end - want)) : nullptr;
+      cut[k] = nl ? nl + 1 : end;
+    }
+    std::vector<ObjChunk> chunks(nt);
+    {
+      std::vector<std::thread> th;
+      // (a run that ends just behind a '\n' sees one empty extra line at its end: ignored like every empty line)
+      auto run = [&](unsigned k) { obj_parse_lines(cut[k], cut[k + 1], chunks[k]); };
+      for (unsigned k = 1; k < nt; k++) th.emplace_back(run, k);
+      run(0);
+      for (auto& t : th) t.join();
+    }
+    ObjRows V, N;
+    std::vector<double> vidx, nidx;
+    if (nt == 1) {
+      V = std::move(chunks[0].V), N = std::move(chunks[0].N), vidx = std::move(chunks[0].vidx), nidx = std::move(chunks[0].nidx);
+    } else {
+      auto merge_rows = [&](ObjRows& dst, ObjRows ObjChunk::*m) {
+        size_t nd = 0, nr = 0;
+        for (auto& c : chunks) nd += (c.*m).data.size(), nr += (c.*m).rows();
+        dst.data.reserve(nd);
+        dst.offset.reserve(nr + 1);
+        for (auto& c : chunks) {
+          const ObjRows& r = c.*m;
+          const uint32_t base = (uint32_t)dst.data.size();
+          dst.data.insert(dst.data.end(), r.data.begin(), r.data.end());
+          for (size_t i = 1; i < r.offset.size(); i++) dst.offset.push_back(base + r.offset[i]);
         }
-      }
-      if (!nl) break;
-      p = nl + 1;
+      };
+      merge_rows(V, &ObjChunk::V);
+      merge_rows(N, &ObjChunk::N);
+      for (auto& c : chunks) vidx.insert(vidx.end(), c.vidx.begin(), c.vidx.end()), nidx.insert(nidx.end(), c.nidx.begin(), c.nidx.end());
     }
     auto flatten = [](const ObjRows& R, const std::vector<double>& idx, float** out, size_t* n) -> int {
-      std::vector<float> flat;
-      flat.reserve(idx.size() * 3);
-      for (double d : idx) {
-        // array[v] with v not a valid index is `undefined`; .flat(1) keeps it as one element -> NaN in the Float32Array
-        if (!(d >= 0) || d != std::floor(d) || d >= (double)R.rows()) {
-          flat.push_back(NAN);
-          continue;
-        }
-        size_t r = (size_t)d;
-        for (uint32_t k = R.offset[r]; k < R.offset[r + 1]; k++) flat.push_back((float)R.data[k]);
+      // array[v] with v not a valid index is `undefined`; .flat(1) keeps it as one element -> NaN in the Float32Array
+      auto valid = [&](double d) { return d >= 0 && d == std::floor(d) && d < (double)R.rows(); };
+      const unsigned nt = host_threads(idx.size(), (size_t)1 << 18);
+      std::vector<size_t> start(nt + 1, 0);
+      const size_t per = (idx.size() + nt - 1) / std::max(1u, nt);
+      auto count = [&](unsigned k) {
+        size_t c = 0;
+        for (size_t i = std::min(idx.size(), k * per), e = std::min(idx.size(), (k + 1) * per); i < e; i++)
+          c += valid(idx[i]) ? (size_t)(R.offset[(size_t)idx[i] + 1] - R.offset[(size_t)idx[i]]) : 1;
+        start[k + 1] = c;
+      };
+      {
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < nt; k++) th.emplace_back(count, k);
+        count(0);
+        for (auto& t : th) t.join();
       }
-      *n = flat.size();
-      if (flat.empty()) return PTMI_OK;
-      *out = (float*)malloc(flat.size() * sizeof(float));
-      if (!*out) return PTMI_ERR_NO_MEMORY;
-      memcpy(*out, flat.data(), flat.size() * sizeof(float));
+      for (unsigned k = 0; k < nt; k++) start[k + 1] += start[k];
+      *n = start[nt];
+      if (*n == 0) return PTMI_OK;
+      float* flat = (float*)malloc(*n * sizeof(float));
+      if (!flat) return PTMI_ERR_NO_MEMORY;
+      auto fill = [&](unsigned k) {
+        float* o = flat + start[k];
+        for (size_t i = std::min(idx.size(), k * per), e = std::min(idx.size(), (k + 1) * per); i < e; i++) {
+          if (!valid(idx[i])) {
+            *o++ = NAN;
+            continue;
+          }
+          const size_t r = (size_t)idx[i];
+          for (uint32_t j = R.offset[r]; j < R.offset[r + 1]; j++) *o++ = (float)R.data[j];
+        }
+      };
+      {
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < nt; k++) th.emplace_back(fill, k);
+        fill(0);
+        for (auto& t : th) t.join();
+      }
+      *out = flat;
       return PTMI_OK;
     };
     int rc = flatten(V, vidx, vertices_out, n_vertices);
