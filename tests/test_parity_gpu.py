@@ -695,6 +695,49 @@ def test_scene_bvh_on_the_device_refuses_more_triangles_than_f32_node_ids_can_na
         ctx.build_scene_bvh()
 
 
+CARRY_CASES = [
+    # name, camera, W, H, frames, params — scenes with triangles, every kind of shade kernel (progressive, importance sampling, NUM_SAMPLES > 1), the Q7 abort
+    ("c2m", "cornell", 192, 128, 3, dict(max_bounces=12, stack_size=20)),
+    ("default", "default", 180, 120, 3, dict(max_bounces=16)),
+    ("c2m", "oblique", 160, 96, 2, dict(max_bounces=8, importance_sampling=1)),
+    ("c2m", "cornell", 96, 64, 2, dict(max_bounces=5, num_samples=4, stratify=1)),
+    ("c2", "oblique", 128, 72, 2, dict(max_bounces=8, stack_size=4)),
+    ("c2", "cornell", 96, 64, 2, dict(max_bounces=2)),
+]
+
+
+@pytest.mark.parametrize("after,slots", [(1, 64), (3, 4096)], ids=["carry-at-once-pool-of-64", "carry-after-3"])
+def test_rays_carried_into_the_next_step_change_nothing(pkg, oracle, monkeypatch, pipeline, after, slots):
+    """Carry (csrc/ptmi_device.h): a k_bvh wave that has found the queue exhausted goes on for PTMI_BVH_CARRY iterations and then moves its unfinished rays
+    into the next step's queue, traversal state (state word, stack, closest hit) in a pool record; the next launch — or k_tail, or the final drain —
+    resumes them.  Forced here on small batches (the library carries only on deep trees and batches of millions of paths) with the wave giving up at
+    once and a pool of 64 records (most rays find it full and are traced to the end after all) and after 3 iterations with room for all: the same
+    framebuffer bits and the same exact counters as the oracle, through the per-bounce kernels alone and with k_tail's hand-over."""
+    if pipeline == "tail":
+        pytest.skip("k_tail from step 0 never launches k_bvh")
+    for k, v in (("PTMI_BVH_CARRY", after), ("PTMI_BVH_CARRY_SLOTS", slots), ("PTMI_BVH_CARRY_MIN_PATHS", 0), ("PTMI_BVH_CARRY_MIN_DEPTH", 0)):
+        monkeypatch.setenv(k, str(v))
+    with pkg.Context(0) as ctx:  # (the tuning variables are read when a context is created)
+        cases = [(n, pkg.scenes.golden_buffers(n), cam, w, h, f, p) for n, cam, w, h, f, p in CARRY_CASES]
+        big = pkg.scenes.c3_scene(60000).buffers(native=pkg.ptmi.NativeHost())  # a deep tree: long traversals, spilled stack entries travel through the pool
+        cases.append(("c3-60k", big, "cornell", 200, 112, 2, dict(max_bounces=6, stack_size=24)))
+        for name, b, cam, w, h, frames, params in cases:
+            view = cornell_view(pkg, cam)
+            ctx.upload_scene(b)
+            ctx.set_params(**params)
+            ctx.resize(w, h)
+            ctx.reset_stats()
+            ctx.set_counters(True)
+            ctx.render(view, 1, frames)
+            got = ctx.read_framebuffer()
+            st = ctx.stats()
+            ctx.set_counters(False)
+            want, ost = oracle.render(b, w, h, view, 1, frames, **_oracle_params(params))
+            assert_same_bits(got, want, "%s with rays carried over (after %d, %d slots)" % (name, after, slots))
+            for k in ("rays", "paths", "node_visits", "tri_tests", "sphere_tests", "quad_tests", "mat_fetches"):
+                assert st[k] == ost[k], (name, k, st[k], ost[k])
+
+
 def _two_mesh_scene(pkg):
     """Deterministic: the Cornell walls + two small procedural meshes with different (rotated, non-uniformly scaled, translated) transforms."""
     import math

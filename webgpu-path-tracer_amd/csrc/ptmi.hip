@@ -125,6 +125,11 @@ struct Tuning {
   int bvh_teams = 16;          // PTMI_BVH_TEAMS: claim counters of k_bvh
   int refill = kRefillThreshold, leaf_batch = kLeafBatch, bvh_range = (int)kBvhRange;  // PTMI_REFILL, PTMI_LEAF_BATCH, PTMI_BVH_RANGE
   int tail_waves_per_cu = 16;  // PTMI_TAIL_WAVES_PER_CU
+  int bvh_carry = 32;          // PTMI_BVH_CARRY: iterations a k_bvh wave goes on after the queue is exhausted before it carries its unfinished rays into the next
+                               // step's queue (Carry, ptmi_device.h); 0 = never (every launch traces its longest ray to the end)
+  int bvh_carry_slots = 1 << 18;  // PTMI_BVH_CARRY_SLOTS: the queues' carry prefix
+  int bvh_carry_last = 0;      // PTMI_BVH_CARRY_LAST: the last this-many steps carry nothing over (measured: 0 is best — the drain launch costs 1.5-2.5 ms either way)
+  int bvh_carry_min_paths = 4 << 20, bvh_carry_min_depth = 12;  // PTMI_BVH_CARRY_MIN_PATHS / _MIN_DEPTH: batches and trees below these are traced without carrying (tests: 0)
   int sort = -1;               // PTMI_SORT: k_shade sorts its chunks by material class (-1 = when the scene has more than one)
   int shade_blocks_per_cu = 0; // PTMI_SHADE_BLOCKS_PER_CU (0 = from the variant's occupancy)
   int tail_limit = -1;         // PTMI_TAIL_LIMIT: k_tail takes queues of at most this many slots (-1 = kTailLimitFirst / kTailLimitLater, 0 = never)
@@ -177,6 +182,7 @@ struct ptmi_ctx {
   size_t slot_cap = 0;  // slots per queue buffer (paths + room for the holes k_shade's regions leave)
   DBuf d_q0[2], d_q1[2], d_q2[2], d_tp[2], d_hm[2];  // slot-indexed live state and hit records, ping-pong
   DBuf d_uv, d_acc, d_pixsum, d_touched, d_ctl, d_totals, d_scratch, d_spill, d_heads;
+  DBuf d_carry[2];  // Carry: the pools of saved traversal state, ping-pong like the queues
 #ifdef PTMI_EXPERIMENTS
   DBuf d_diag[4];  // PTMI_DIAG_SORT: keys / slots, in / out
 #endif
@@ -578,7 +584,7 @@ int ensure_paths(ptmi_ctx* c, size_t npaths, int n_ctl, bool need_pixsum) {
   if (npaths > c->path_cap) {
     // A queue holds at most `npaths` paths plus the holes of k_shade's output regions: at most one region per block
     // (region <= slots/grid/16 rounded up to 512) — 1/8 of the paths plus 1024 slots per possible block is ample.
-    const size_t slots = npaths + npaths / 8 + (size_t)c->num_cus * 8 * 1024;
+    const size_t slots = npaths + npaths / 8 + (size_t)c->num_cus * 8 * 1024 + (size_t)c->tun.bvh_carry_slots;  // (+ the carry prefix, Carry)
     c->path_cap = 0;  // a failed allocation below leaves some buffers released: nothing may be assumed allocated then
     c->slot_cap = 0;
     c->pixsum_alloc = false;
@@ -729,6 +735,11 @@ void load_tuning(ptmi_ctx* c) {
   t.leaf_batch = env_int("PTMI_LEAF_BATCH", t.leaf_batch);
   t.bvh_range = std::max(64, std::min(1 << 16, env_int("PTMI_BVH_RANGE", t.bvh_range))) & ~63;
   t.tail_waves_per_cu = std::max(1, std::min(32, env_int("PTMI_TAIL_WAVES_PER_CU", t.tail_waves_per_cu)));
+  t.bvh_carry = std::max(0, env_int("PTMI_BVH_CARRY", t.bvh_carry));
+  t.bvh_carry_slots = std::max(64, std::min(1 << 22, env_int("PTMI_BVH_CARRY_SLOTS", t.bvh_carry_slots)));
+  t.bvh_carry_last = std::max(0, env_int("PTMI_BVH_CARRY_LAST", t.bvh_carry_last));
+  t.bvh_carry_min_paths = std::max(0, env_int("PTMI_BVH_CARRY_MIN_PATHS", t.bvh_carry_min_paths));
+  t.bvh_carry_min_depth = std::max(0, env_int("PTMI_BVH_CARRY_MIN_DEPTH", t.bvh_carry_min_depth));
   t.sort = env_int("PTMI_SORT", -1);
   t.shade_blocks_per_cu = env_int("PTMI_SHADE_BLOCKS_PER_CU", 0);
   t.tail_limit = env_int("PTMI_TAIL_LIMIT", -1);
@@ -745,7 +756,7 @@ void load_tuning(ptmi_ctx* c) {
 
 // hitScene, part 2 for the step's queue (k_bvh).  Part 1 has already been run by whoever created the rays (k_generate,
 // k_shade); ptmi_trace's rays come from the host, so it asks for k_prims first.
-int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_items, bool with_prims, const RenderConst* first_rc = nullptr) {
+int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_items, bool with_prims, const RenderConst* first_rc = nullptr, const Carry& cy = Carry{}) {
   unsigned long long* tot = c->d_totals.as<unsigned long long>();
   const uint32_t pgrid = std::max<uint32_t>(1, std::min<uint32_t>((max_items + kBlock - 1) / kBlock, (uint32_t)c->num_cus * 32));
   if (with_prims) {
@@ -815,7 +826,7 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
                      leaf_batch, tot, cam)
 #define PTMI_LAUNCH_BVH_K(KERNEL)                                                                                                                                     \
   hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), n_teams, c->prm.stack_size, le, se, c->d_spill.as<int2>(), thr, \
-                     leaf_batch, tot, range_cap, cam, diag_order, diag_keys)
+                     leaf_batch, tot, range_cap, cam, cy, diag_order, diag_keys)
 #define PTMI_LAUNCH_BVH(CNT, NA)                                       \
   do {                                                                 \
     if (edition == 1) PTMI_LAUNCH_BVH_K1((k_bvh<CNT, NA>));           \
@@ -825,7 +836,7 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
 #else
 #define PTMI_LAUNCH_BVH(CNT, NA)                                                                                                                                       \
   hipLaunchKernelGGL((k_bvh2<CNT, NA, false>), dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), n_teams, c->prm.stack_size, le, se, \
-                     c->d_spill.as<int2>(), thr, leaf_batch, tot, range_cap, cam)
+                     c->d_spill.as<int2>(), thr, leaf_batch, tot, range_cap, cam, cy)
 #endif
   if (c->counters) {
     if (noabort) PTMI_LAUNCH_BVH(true, true);
@@ -844,19 +855,19 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
 }
 
 // k_tail in front of a step: traces the step's queue to the end if it is short (PTMI_TAIL_LIMIT slots, 0 = never launched), else returns at once.
-int launch_tail(ptmi_ctx* c, const RenderConst& rc, const Paths& P, StepCtl* ctl, int first, uint32_t limit) {
+int launch_tail(ptmi_ctx* c, const RenderConst& rc, const Paths& P, StepCtl* ctl, int first, uint32_t limit, const Carry& cy) {
   const int sa = stack_alloc_for(c);
   const int le = std::min(sa, c->tun.lds_stack);
   const int se = sa - le;
   const size_t lds = (size_t)le * 2 * 64 * sizeof(int);
   const bool noabort = c->bvh_depth < c->prm.stack_size && c->tun.noabort;
   const int waves_per_cu = c->tun.tail_waves_per_cu;
-  const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>((limit + 63) / 64, (uint32_t)c->num_cus * (uint32_t)waves_per_cu));
+  const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)limit + 63) / 64, (uint64_t)c->num_cus * (uint64_t)waves_per_cu));
   HIP_TRY(c, c->d_spill.ensure(std::max<size_t>(16, (size_t)c->num_cus * 32 * (size_t)se * 64 * sizeof(int2))));  // (k_bvh's grids are no larger: one size for both)
   unsigned long long* tot = c->d_totals.as<unsigned long long>();
   ScopedSpan sp(c, T_TAIL);
 #define PTMI_LAUNCH_TAIL(IS, CN, MU, NA) \
-  hipLaunchKernelGGL((k_tail<IS, CN, MU, NA>), dim3(grid), dim3(64), lds, c->stream, c->S, rc, P, ctl, tot, first, limit, c->prm.stack_size, le, se, c->d_spill.as<int2>())
+  hipLaunchKernelGGL((k_tail<IS, CN, MU, NA>), dim3(grid), dim3(64), lds, c->stream, c->S, rc, P, ctl, tot, first, limit, c->prm.stack_size, le, se, c->d_spill.as<int2>(), cy)
 #define PTMI_LAUNCH_TAIL3(IS, CN, MU)          \
   do {                                         \
     if (noabort) PTMI_LAUNCH_TAIL(IS, CN, MU, true); \
@@ -884,9 +895,9 @@ int launch_tail(ptmi_ctx* c, const RenderConst& rc, const Paths& P, StepCtl* ctl
 
 // progressive mode without importance sampling is k_shade6 (80 VGPRs); the k_shade instances for it are never made
 template <bool IS, bool SO, bool CN, bool MU>
-void launch_shade(ptmi_ctx* c, uint32_t sgrid, const RenderConst& rc, const Paths& P, StepCtl* ctl, unsigned long long* tot, int first) {
-  if constexpr (!IS && !MU) hipLaunchKernelGGL((k_shade6<SO, CN>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl, c->d_heads.as<uint32_t>(), tot, first);
-  else hipLaunchKernelGGL((k_shade<IS, SO, CN, MU>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl, c->d_heads.as<uint32_t>(), tot, first);
+void launch_shade(ptmi_ctx* c, uint32_t sgrid, const RenderConst& rc, const Paths& P, StepCtl* ctl, unsigned long long* tot, int first, uint32_t resv) {
+  if constexpr (!IS && !MU) hipLaunchKernelGGL((k_shade6<SO, CN>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl, c->d_heads.as<uint32_t>(), tot, first, resv);
+  else hipLaunchKernelGGL((k_shade<IS, SO, CN, MU>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl, c->d_heads.as<uint32_t>(), tot, first, resv);
 }
 
 // `fold` = how many of the batch's leading frames are added to the framebuffer now (-1 = all of them)
@@ -937,7 +948,25 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   if (rcode) return rcode;  // nothing is on the stream yet: ptmi_render may retry with a smaller batch
   StepCtl* ctl = c->d_ctl.as<StepCtl>();
   const uint32_t total = rc.n_local * (uint32_t)n_frames;
-  const uint32_t bound = total + total / 8 + (uint32_t)c->num_cus * 8 * 1024;  // slots a step's queue can span
+  // Carry (ptmi_device.h): rays that outlive their k_bvh launch move into the next step's queue.  Worth it where a launch's longest ray is long
+  // against the launch — deep trees, batches of millions of paths; a shallow tree's tail is microseconds, and small batches belong to k_tail anyway.
+  const int sa_carry = stack_alloc_for(c);
+  const bool carry = c->tun.bvh_carry > 0 && c->S.n_nodes > 0 && c->bvh_depth >= c->tun.bvh_carry_min_depth && total >= (uint32_t)c->tun.bvh_carry_min_paths && p.max_bounces > 1;
+  const uint32_t resv = carry ? (uint32_t)c->tun.bvh_carry_slots : 0u;
+  const int rec_words = 8 + 2 * sa_carry;
+  if (carry)
+    for (int k = 0; k < 2; k++) HIP_TRY(c, c->d_carry[k].ensure((size_t)resv * (size_t)rec_words * 4));
+  auto carry_of = [&](int s) {  // what step s's kernels need to know: its queue's prefix, the next one's, the two pools
+    Carry cy{};
+    cy.resv = s == 0 ? 0u : resv;
+    cy.resv_next = resv;
+    cy.after = c->tun.bvh_carry;
+    cy.rec_words = rec_words;
+    cy.pool_in = c->d_carry[s & 1].as<uint32_t>();
+    cy.pool_out = c->d_carry[(s + 1) & 1].as<uint32_t>();
+    return cy;
+  };
+  const uint32_t bound = total + total / 8 + (uint32_t)c->num_cus * 8 * 1024 + resv;  // slots a step's queue can span
   const uint32_t ew_grid = std::max<uint32_t>(1, std::min<uint32_t>((total + kBlock - 1) / kBlock, (uint32_t)c->num_cus * 16));
   // k_shade sorts its chunks by material class only when the scene has more than one (PTMI_SORT=0/1 overrides, for A/B runs)
   const int sort_env = c->tun.sort;
@@ -966,7 +995,7 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
 
   ScopedSpan whole(c, T_RENDER);
   c->batch_enqueued = true;  // from here on a failure leaves a partly traced batch behind: never retried
-  HIP_TRY(c, hipMemsetAsync(ctl, 0, (size_t)(n_steps + 2) * sizeof(StepCtl), c->stream));
+  hipLaunchKernelGGL(k_init_ctl, dim3((unsigned)((n_steps + 2 + 63) / 64)), dim3(64), 0, c->stream, ctl, n_steps + 2, resv);  // n_rays = the carry prefix (0 for step 0)
   HIP_TRY(c, hipMemsetAsync(tot + 16, 0, kTotalsBytes - 128, c->stream));  // the batch's hitScene tally
   {
     ScopedSpan s(c, T_GENERATE);
@@ -976,30 +1005,41 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
     HIP_TRY(c, hipGetLastError());
     c->stats.generate_launches++;
   }
+  bool drained = false;
   for (int s = 0; s < n_steps; s++) {
     // With the reference's MAX_BOUNCES = 100 nearly all steps run on an empty queue (Russian roulette ends paths after
     // a dozen bounces): from step 12 on, look at the queue length every 8 steps and stop enqueuing once it is empty.
     if (s >= 12 && (s & 7) == 4) {
       uint32_t left = 1;
-      HIP_TRY(c, hipMemcpyAsync(&left, &ctl[s].n_rays, sizeof left, hipMemcpyDeviceToHost, c->stream));
+      uint32_t rec3[3] = {1, 0, 0};  // n_rays, tail_done, n_carried
+      HIP_TRY(c, hipMemcpyAsync(rec3, &ctl[s].n_rays, sizeof rec3, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
-      if (left == 0) break;
+      left = (rec3[0] <= resv && rec3[2] == 0) ? 0u : 1u;
+      if (left == 0) {
+        drained = true;
+        break;
+      }
     }
     Paths P = paths_of(c, s, rc.num_samples > 1);
     if (const uint32_t tail_limit = s == 0 ? tail_limit_first : tail_limit_later) {
-      int lr = launch_tail(c, rc, P, ctl + s, s == 0 ? 1 : 0, tail_limit);
+      int lr = launch_tail(c, rc, P, ctl + s, s == 0 ? 1 : 0, tail_limit, carry_of(s));
       if (lr) return lr;
       // step 0's queue is the whole batch (k_generate fills one slot per path): if that fits the limit k_tail has just been handed all of it —
       // nothing is left for the per-bounce kernels, and a lone frame is three launches instead of 3 x MAX_BOUNCES + 2
-      if (s == 0 && total <= tail_limit) break;
+      if (s == 0 && total <= tail_limit) {
+        drained = true;
+        break;
+      }
     }
     {
-      int lr = launch_intersect(c, P, ctl + s, bound, false, s == 0 ? &rc : nullptr);
+      Carry cy = carry_of(s);
+      if (!carry || s >= n_steps - c->tun.bvh_carry_last) cy.resv_next = 0u;
+      int lr = launch_intersect(c, P, ctl + s, bound, false, s == 0 ? &rc : nullptr, cy);
       if (lr) return lr;
     }
     {
       ScopedSpan sp(c, T_SHADE);
-#define PTMI_LAUNCH_SHADE(IS, SO, CN, MU) launch_shade<IS, SO, CN, MU>(c, sgrid, rc, P, ctl + s, tot, s == 0 ? 1 : 0)
+#define PTMI_LAUNCH_SHADE(IS, SO, CN, MU) launch_shade<IS, SO, CN, MU>(c, sgrid, rc, P, ctl + s, tot, s == 0 ? 1 : 0, s == 0 ? 0u : resv)
 #define PTMI_LAUNCH_SHADE2(IS, SO)                          \
   do {                                                      \
     if (rc.num_samples > 1) {                               \
@@ -1023,6 +1063,12 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
     }
     c->stats.intersect_launches++;
     c->stats.shade_launches++;
+  }
+  if (carry && !drained && n_steps > 0) {
+    // paths that were carried over lag behind the step count: whatever the last k_shade left in the queue (and what the last k_bvh carried) is
+    // traced to its end by one k_tail launch — a few thousand paths at most
+    int lr = launch_tail(c, rc, paths_of(c, n_steps, rc.num_samples > 1), ctl + n_steps, 0, 0xffffffffu, carry_of(n_steps));
+    if (lr) return lr;
   }
   {
     ScopedSpan s(c, T_ACCUM);
@@ -1424,7 +1470,7 @@ void ptmi_destroy(ptmi_ctx* c) {
   for (DBuf* b : {&c->d_quad_unit_n, &c->d_spheres, &c->d_sphere_info, &c->d_quads, &c->d_quad_mat, &c->d_tris, &c->d_pretri, &c->d_trinorm, &c->d_meshes, &c->d_xforms,
                   &c->d_mats, &c->d_pairs, &c->d_leaf_table, &c->d_fb_own, &c->d_q0[0], &c->d_q0[1], &c->d_q1[0], &c->d_q1[1], &c->d_q2[0],
                   &c->d_q2[1], &c->d_tp[0], &c->d_tp[1], &c->d_hm[0], &c->d_hm[1], &c->d_uv, &c->d_acc, &c->d_pixsum, &c->d_touched, &c->d_ctl, &c->d_totals,
-                  &c->d_scratch, &c->d_spill, &c->d_heads, &c->d_fb_gather, &c->d_fb_stage, &c->d_bvh_rows})
+                  &c->d_scratch, &c->d_spill, &c->d_heads, &c->d_fb_gather, &c->d_fb_stage, &c->d_bvh_rows, &c->d_carry[0], &c->d_carry[1]})
     b->release();
 #ifdef PTMI_EXPERIMENTS
   for (DBuf& b : c->d_diag) b.release();

@@ -276,9 +276,25 @@ struct Paths {
 // One 128-byte line per step: k_shade's blocks and waves claim their output regions of the NEXT step's queue with atomics on n_rays, and
 // same-line atomics serialise in one L2 channel at ~11 ns each — nothing else may share the line.
 struct alignas(128) StepCtl {
-  uint32_t n_rays;  // slots of this step's queue (holes included)
-  uint32_t pad[31];
+  uint32_t n_rays;     // slots of this step's queue (holes and the carry prefix included)
+  uint32_t tail_done;  // k_tail: blocks that have finished (the last one closes the queue)
+  uint32_t n_carried;  // rays the previous step's k_bvh carried over into slots [0, n_carried) of this queue (Carry)
+  uint32_t pad[29];
 };
+// Rays that outlive their k_bvh launch.  Every launch used to end with a tail as long as its longest ray (~1 ms per launch on an 871 k-triangle tree whatever
+// the batch size: 8-10 % of the kernel).  Paths are independent, so a path may lag a step behind: a wave that has found the queue exhausted goes on for
+// `after` iterations and then CARRIES its unfinished rays over — path state into a slot of the NEXT step's queue, traversal state (state word, stack,
+// closest hit so far) into a record of the pool — and the next launch picks them up first, among all its other rays.  Slots [0, resv) of every queue but
+// step 0's are reserved for them; [n_carried, resv) hold nothing and every reader of a queue skips them.  Same visits, same outcomes, same counters — only later.
+struct Carry {
+  uint32_t resv;       // reserved prefix of THIS queue
+  uint32_t resv_next;  // of the next one; 0 = this launch carries nothing over
+  int after;           // iterations a wave goes on after the queue is exhausted
+  int rec_words;       // words per pool record: 8 (state word, sp, closest t, u, v, prim, material word, -) + 2 per stack entry
+  uint32_t* pool_in;   // records of this queue's carried rays, by slot
+  uint32_t* pool_out;  // records of the next queue's
+};
+DEV bool dead_slot(uint32_t slot, uint32_t n_carried, uint32_t resv) { return slot >= n_carried && slot < resv; }
 // The hitScene tally of the batch being traced (slots that held a path, summed over its steps) is spread over kTallyLines counters on
 // lines of their own behind the 16 persistent totals (zeroed when a batch starts, added up by the k_accumulate call that folds its slot 0).
 constexpr int kTallyLines = 32;

@@ -282,7 +282,8 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
 template <bool COUNT, bool NOABORT, bool UNIFIED>
 __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads, uint32_t n_teams, int stack_size,
                                                            int lds_entries, int spill_entries, int2* __restrict__ spill, int refill_threshold, int leaf_batch,
-                                                           unsigned long long* __restrict__ totals, uint32_t range_cap, float4 cam  // cam.w != 0: step 0's queue — every ray starts at cam.xyz
+                                                           unsigned long long* __restrict__ totals, uint32_t range_cap, float4 cam,  // cam.w != 0: step 0's queue — every ray starts at cam.xyz
+                                                           Carry cy
 #ifdef PTMI_EXPERIMENTS
                                                            , const uint32_t* __restrict__ diag_order, const uint32_t* __restrict__ diag_keys
 #endif
@@ -297,13 +298,17 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, 
   stk.spill = spill + (size_t)blockIdx.x * (size_t)spill_entries * 64 + lane;
   stk.lds_entries = lds_entries;
   uint32_t* cand = reinterpret_cast<uint32_t*>(lds_stack + lds_entries * 2 * 64);  // [128] candidate slots
-  const uint32_t n = ctl->n_rays;
+  const uint32_t n_carried = cy.resv ? min(ctl->n_carried, cy.resv) : 0u;  // slots [0, n_carried) hold rays the previous launch carried over, [n_carried, resv) nothing
+  uint32_t n = ctl->n_rays;
+  if (n <= cy.resv && n_carried == 0u) n = 0u;  // nothing but the empty carry prefix
   const uint32_t range = min(range_cap, max(64u, ((n / (2u * gridDim.x)) + 63u) & ~63u));
   const uint32_t team = blockIdx.x % n_teams;
   Counters cn = {0, 0, 0, 0, 0};
   uint32_t rb = 0, re = 0;   // this wave's claimed range of slots still to be scanned (wave-uniform)
   uint32_t ncand = 0;        // candidates waiting in `cand` (wave-uniform)
   bool exhausted = (n == 0);
+  int tail_iters = 0;        // iterations since this wave found the queue exhausted (wave-uniform)
+  bool may_carry = cy.resv_next != 0u;
   // the lane's ray
   uint32_t node = N_DONE, myslot = 0, negmask = 0;
   int sp = 0;
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, 
           if (flagged) slot = diag_order[slot];
         } else
 #endif
-          flagged = slot < re && (P.hin.mat[slot] & HITMAT_BVH) != 0u;
+          flagged = slot < re && !dead_slot(slot, n_carried, cy.resv) && (P.hin.mat[slot] & HITMAT_BVH) != 0u;
         const uint64_t fm = __ballot(flagged);
         if (flagged) cand[ncand + lanes_below(fm)] = slot;
         ncand += (uint32_t)__popcll(fm);
@@ -376,6 +381,14 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, 
           hit.prim = 0u;
           has = true;
           node = root_node;
+          if (myslot < cy.resv) {  // a ray the previous launch carried over: its traversal goes on where it stopped
+            const uint32_t* rec = cy.pool_in + (size_t)myslot * (size_t)cy.rec_words;
+            node = rec[0];
+            sp = (int)rec[1];
+            ct = __uint_as_float(rec[2]);
+            hit.u = __uint_as_float(rec[3]), hit.v = __uint_as_float(rec[4]), hit.prim = rec[5], hit.mat = rec[6];
+            for (int e = 0; e < sp; e++) stack2_write(stk, e, rec[8 + 2 * e], __uint_as_float(rec[9 + 2 * e]));
+          }
         }
         ncand -= take;
         hm = __ballot(node != N_DONE);
@@ -448,7 +461,41 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, 
         if (node == N_POP) node = pop_until_pass2(stk, sp, ct, cn, COUNT);
       }
       working = __popcll(__ballot(node != N_DONE));
+      if (!more && may_carry && ++tail_iters >= cy.after) break;  // (wave-uniform)
     } while (working >= min_working);
+    }
+    if (!more && may_carry && tail_iters >= cy.after) {
+      // The queue is exhausted and this wave has gone on for `after` iterations: what it still holds are the launch's long rays.  Each one moves
+      // into a slot of the next step's queue with its traversal state in the pool; its slot here becomes a hole, so this step's k_shade passes it by.
+      bool failed = false;
+      if (node != N_DONE) {
+        const uint32_t ns = atomicAdd(&ctl[1].n_carried, 1u);
+        if (ns < cy.resv_next) {
+          const float4 r1 = P.in.q1[myslot];
+          float4 r0 = cam, r2 = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0));  // (step 0's queue stores neither the origin nor the initial throughput / bounce)
+          if (cam.w == 0.0f) r0 = P.in.q0[myslot], r2 = P.in.q2[myslot];
+          else r0.w = __uint_as_float(rng0_of(P)[myslot]);
+          P.out.q0[ns] = r0, P.out.q1[ns] = r1, P.out.q2[ns] = r2;
+          P.hout.tp[ns] = P.hin.tp[myslot];    // hitScene part 1's record: stands unless a triangle has won or wins later
+          P.hout.mat[ns] = P.hin.mat[myslot];  // (HITMAT_BVH still set)
+          uint32_t* rec = cy.pool_out + (size_t)ns * (size_t)cy.rec_words;
+          rec[0] = node, rec[1] = (uint32_t)sp, rec[2] = __float_as_uint(ct), rec[3] = __float_as_uint(hit.u), rec[4] = __float_as_uint(hit.v), rec[5] = hit.prim, rec[6] = hit.mat;
+          for (int e = 0; e < sp; e++) {
+            uint32_t w0;
+            float w1;
+            stack2_read(stk, e, w0, w1);
+            rec[8 + 2 * e] = w0, rec[9 + 2 * e] = __float_as_uint(w1);
+          }
+          reinterpret_cast<uint32_t*>(P.in.q1 + myslot)[3] = PID_HOLE;
+          P.hin.mat[myslot] = HITMAT_HOLE;
+          node = N_DONE;
+          has = false;
+        } else {  // the pool is full: this ray is traversed to its end here after all
+          atomicSub(&ctl[1].n_carried, 1u);
+          failed = true;
+        }
+      }
+      if (__ballot(failed) != 0ull) may_carry = false;
     }
   }
   if (COUNT) reduce_counters(cn, totals, true);
@@ -709,7 +756,7 @@ constexpr int kSChunk = PTMI_SCHUNK;  // slots a k_shade block sorts, shades and
 //      the next region — and marks what is left at the end as holes.
 template <bool IS, bool SORT, bool COUNT, bool MULTI>
 DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads, unsigned long long* __restrict__ totals,
-                    int first) {
+                    int first, uint32_t resv) {
   reset_heads(heads);
   __shared__ float4 s_q0[kSChunk], s_q1[kSChunk], s_q2[kSChunk];
   __shared__ uint16_t s_sorted[SORT ? kSChunk : 1];
@@ -717,7 +764,9 @@ DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, St
   __shared__ uint32_t s_nout, s_next;
   const QuadL L = load_light(S);
   const int lane = lane_id();
-  const uint32_t n = ctl->n_rays;
+  const uint32_t n_carried = resv ? min(ctl->n_carried, resv) : 0u;  // (Carry: slots [n_carried, resv) of this queue hold nothing)
+  uint32_t n = ctl->n_rays;
+  if (n <= resv && n_carried == 0u) n = 0u;
   // region size: a block handles about n / gridDim slots per launch; 1/16 of that per claim keeps both the
   // number of atomics and the holes left at the end (at most one region per block) small
   const uint32_t region = max((uint32_t)kSChunk, ((n / gridDim.x / (uint32_t)PTMI_REGION_DIV) + 511u) & ~511u);
@@ -763,7 +812,7 @@ DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, St
       for (int r = 0; r < kSChunk / kBlock; r++) {
         const uint32_t j = (uint32_t)r * kBlock + threadIdx.x;
         int bin = -1;
-        if (j < m) {
+        if (j < m && !dead_slot(base + j, n_carried, resv)) {
           const uint32_t b = (P.hin.mat[base + j] >> HITMAT_BIN_SHIFT) & 7u;
           if (b < (uint32_t)NUM_BINS) bin = (int)b;  // 7 = hole
         }
@@ -831,7 +880,7 @@ DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, St
       ns.o = ns.d = ns.T = mk3(0, 0, 0);
       ns.bounce = 0, ns.rng = 0, ns.pid = 0;
 #endif
-        if (j < m) {
+        if (j < m && !dead_slot(base + j, n_carried, resv)) {
           const SlotState st = load_slot(P, base + j, first != 0, rc);
           valid = __float_as_uint(st.q1.w) != PID_HOLE;
           if (valid) {
@@ -958,7 +1007,7 @@ DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, St
 // (shade_body's three barriers per chunk had every wave wait for the block's slowest three times per 128 slots of its own work.)
 template <bool IS, bool COUNT, bool MULTI>
 DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads,
-                         unsigned long long* __restrict__ totals, int first) {
+                         unsigned long long* __restrict__ totals, int first, uint32_t resv) {
   reset_heads(heads);
   constexpr uint32_t kRing = 128, kWaves = kBlock / 64;
   static_assert((size_t)kWaves * kRing == (size_t)kSChunk, "the rings take the LDS the block version's staging arrays take");
@@ -974,7 +1023,9 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
   const int lane = lane_id();
   const uint32_t wv = threadIdx.x >> 6;
   float4 *const r0 = s_q0 + wv * kRing, *const r1 = s_q1 + wv * kRing, *const r2 = s_q2 + wv * kRing;
-  const uint32_t n = ctl->n_rays;
+  const uint32_t n_carried = resv ? min(ctl->n_carried, resv) : 0u;  // (Carry: slots [n_carried, resv) of this queue hold nothing)
+  uint32_t n = ctl->n_rays;
+  if (n <= resv && n_carried == 0u) n = 0u;
   const uint32_t region = max((uint32_t)kSChunk, ((n / gridDim.x / (uint32_t)PTMI_REGION_DIV) + 511u) & ~511u);
   const uint32_t wregion = region / kWaves;
   uint32_t w_cur = 0, w_rend = 0;  // this wave's current output region of the next queue (wave-uniform)
@@ -1073,7 +1124,7 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
       NewState ns;  // (zeroed although only the survivors' values are read: left undefined, the allocator needs 8 registers more — scratch at 80 VGPRs)
       ns.o = ns.d = ns.T = mk3(0, 0, 0);
       ns.bounce = 0, ns.rng = 0, ns.pid = 0;
-      if (j < m) {
+      if (j < m && !dead_slot(base + j, n_carried, resv)) {
         LT(LT_GROUP);
         const SlotState st = load_slot(P, base + j, first != 0, rc);
         valid = __float_as_uint(st.q1.w) != PID_HOLE;
@@ -1118,15 +1169,15 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
 // latency-bound kernel turns into throughput (round 3: 5 -> 6 blocks per CU, -8 %) —, the others need up to 96 (5 waves; at 80 they spill).
 template <bool IS, bool SORT, bool COUNT, bool MULTI>
 __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads,
-                                                                  unsigned long long* __restrict__ totals, int first) {
-  if (SORT || PTMI_SHADE_WAVE == 0) shade_body<IS, SORT, COUNT, MULTI>(S, rc, P, ctl, heads, totals, first);
-  else shade_body_wave<IS, COUNT, MULTI>(S, rc, P, ctl, heads, totals, first);
+                                                                  unsigned long long* __restrict__ totals, int first, uint32_t resv) {
+  if (SORT || PTMI_SHADE_WAVE == 0) shade_body<IS, SORT, COUNT, MULTI>(S, rc, P, ctl, heads, totals, first, resv);
+  else shade_body_wave<IS, COUNT, MULTI>(S, rc, P, ctl, heads, totals, first, resv);
 }
 template <bool SORT, bool COUNT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_shade6(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl,
-                                                                                                uint32_t* __restrict__ heads, unsigned long long* __restrict__ totals, int first) {
-  if (SORT || PTMI_SHADE_WAVE == 0) shade_body<false, SORT, COUNT, false>(S, rc, P, ctl, heads, totals, first);
-  else shade_body_wave<false, COUNT, false>(S, rc, P, ctl, heads, totals, first);
+                                                                                                uint32_t* __restrict__ heads, unsigned long long* __restrict__ totals, int first, uint32_t resv) {
+  if (SORT || PTMI_SHADE_WAVE == 0) shade_body<false, SORT, COUNT, false>(S, rc, P, ctl, heads, totals, first, resv);
+  else shade_body_wave<false, COUNT, false>(S, rc, P, ctl, heads, totals, first, resv);
 }
 
 // k_tail — a SHORT queue traced to the end in one launch: every lane takes a path and runs ray_color's loop for it (hitScene part 2 on
@@ -1138,9 +1189,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) 
 // Same per-ray arithmetic and visit order as the wavefront kernels (the same device functions), same counters and tallies.
 template <bool IS, bool COUNT, bool MULTI, bool NOABORT>
 __global__ __launch_bounds__(64) void k_tail(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, unsigned long long* __restrict__ totals, int first, uint32_t limit,
-                                             int stack_size, int lds_entries, int spill_entries, int2* __restrict__ spill) {
+                                             int stack_size, int lds_entries, int spill_entries, int2* __restrict__ spill, Carry cy) {
+  const uint32_t n_carried = cy.resv ? min(ctl->n_carried, cy.resv) : 0u;  // (Carry: slots [n_carried, resv) hold nothing, [0, n_carried) rays whose traversal goes on)
   const uint32_t n = ctl->n_rays;
-  if (n == 0u || n > limit) return;
+  if (n <= cy.resv && n_carried == 0u) return;            // empty
+  if ((n > cy.resv ? n - cy.resv : 0u) + n_carried > limit) return;  // too long for this kernel: the per-bounce kernels take the step
   extern __shared__ int lds_stack[];
   const int lane = lane_id();
   LaneStack2 stk;
@@ -1159,6 +1212,7 @@ __global__ __launch_bounds__(64) void k_tail(DevScene S, RenderConst rc, Paths P
   st.tp = make_float2(0.0f, 0.0f);
   st.hitmat = HITMAT_HOLE, st.slot = 0;
   bool alive = false;
+  bool resume = false;  // the lane's path was taken from the carry prefix: its hitScene part 2 goes on from the pool's record (first iteration only)
   float2 uv = make_float2(0.0f, 0.0f);  // barycentrics of the lane's triangle hit (the queue comes from k_generate / k_shade: none in it yet)
   uint32_t gnext = blockIdx.x, gbase = 0, pos = 64;  // next group to open; the open group's first slot and how many of its slots are taken
 #pragma unroll 1
@@ -1175,10 +1229,11 @@ __global__ __launch_bounds__(64) void k_tail(DevScene S, RenderConst rc, Paths P
         const uint32_t take = min(nidle, 64u - pos), rank = lanes_below(~am);
         if (!alive && rank < take) {
           const uint32_t slot = gbase + pos + rank;
-          if (slot < n) {
+          if (slot < n && !dead_slot(slot, n_carried, cy.resv)) {
             st = load_slot(P, slot, first != 0, rc);
             alive = __float_as_uint(st.q1.w) != PID_HOLE;
             uv = make_float2(0.0f, 0.0f);
+            resume = alive && slot < cy.resv;
           }
         }
         pos += take;
@@ -1203,6 +1258,15 @@ __global__ __launch_bounds__(64) void k_tail(DevScene S, RenderConst rc, Paths P
         orr.mesh = -1;
         orr.o = orr.d = o;
         TriHit hit = {0.0f, 0.0f, 0u, 0u};
+        if (flagged && resume) {  // carried over by the last k_bvh launch: state word, stack and the closest hit so far come from the pool
+          const uint32_t* rec = cy.pool_in + (size_t)st.slot * (size_t)cy.rec_words;
+          node = rec[0];
+          sp = (int)rec[1];
+          ct = __uint_as_float(rec[2]);
+          hit.u = __uint_as_float(rec[3]), hit.v = __uint_as_float(rec[4]), hit.prim = rec[5], hit.mat = rec[6];
+          for (int e = 0; e < sp; e++) stack2_write(stk, e, rec[8 + 2 * e], __uint_as_float(rec[9 + 2 * e]));
+        }
+        resume = false;
 #pragma unroll 1
         while (__ballot(node != N_DONE) != 0ull) {
           if ((int)node < 0) {
@@ -1265,8 +1329,20 @@ __global__ __launch_bounds__(64) void k_tail(DevScene S, RenderConst rc, Paths P
   }
   if (lane == 0) {  // whoever finishes last closes the queue (every block has read its length by then)
     __threadfence();
-    if (atomicAdd(&ctl->pad[0], 1u) == gridDim.x - 1u) ctl->n_rays = 0u;
+    if (atomicAdd(&ctl->tail_done, 1u) == gridDim.x - 1u) {
+      ctl->n_rays = 0u;
+      ctl->n_carried = 0u;
+    }
   }
+}
+
+// A batch's step records: every queue but step 0's starts behind its carry prefix (Carry)
+__global__ void k_init_ctl(StepCtl* __restrict__ ctl, int n, uint32_t resv) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n) return;
+  ctl[i].n_rays = i == 0 ? 0u : resv;
+  ctl[i].tail_done = 0u;
+  ctl[i].n_carried = 0u;
 }
 
 // main.wgsl:22-27 for the frame slots [f_begin, f_end) of the batch, in frame order; the call that folds slot 0 also
