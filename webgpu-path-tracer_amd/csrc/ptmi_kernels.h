@@ -732,7 +732,12 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
 #define PTMI_SCHUNK 512
 #endif
 #ifndef PTMI_SHADE_WAVE
-#define PTMI_SHADE_WAVE 1  // A/B: 0 = the unsorted variants run the block version (three barriers per chunk) like the sorted ones
+#define PTMI_SHADE_WAVE 1  // A/B: 0 = every variant runs the block version (three barriers per chunk)
+#endif
+#ifndef PTMI_SHADE_SORT_WAVE
+#define PTMI_SHADE_SORT_WAVE 0  // A/B: 1 = the sorted variants run wave by wave with per-class bins instead of the block version's LDS counting sort and its three
+                                // barriers per 512-slot chunk (round 4: built, bit-exact, 2.5 % SLOWER on configs[4] — 61.3 vs 59.8 ms per 64 spp, profiles/r04_sort_wave_ab.txt:
+                                // the barriers are not what that kernel waits for; the gathers by slot number and the bin bookkeeping cost more than they save)
 #endif
 #ifndef PTMI_REGION_DIV
 #define PTMI_REGION_DIV 16  // A/B: a block's share of the queue is claimed in this many regions (x4: every wave claims its own)
@@ -1005,13 +1010,22 @@ DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, St
 // the same 64-slot groups of the block's chunks as in shade_body, stages its survivors in an LDS ring of its own (128 entries) and runs a
 // flush pass — hitScene part 1 for 64 new rays, all lanes busy — whenever 64 are waiting; what is left goes out in one last, partial pass.
 // (shade_body's three barriers per chunk had every wave wait for the block's slowest three times per 128 slots of its own work.)
-template <bool IS, bool COUNT, bool MULTI>
+//
+// SORT (scenes with several material classes, round 4): the same wave-by-wave loop with BINS in front of it instead of the block version's counting sort and
+// its three barriers per chunk.  A wave reads the material words of its 64-slot group, and the slots whose class is Lambertian, mirror or glass go into a
+// ring of slot numbers per class (3 x 128 x 4 bytes per wave); a class is shaded whenever 64 of its slots wait — one class per pass, all lanes busy, state
+// gathered by slot number from neighbouring groups — and what is left goes out in partial passes at the end.  Misses ride along with the Lambertian class,
+// the rare classes (isotropic media, unknown material types) are shaded at once, with the group.  ONE call site of shade_one for all of it (a work loop that picks a full bin,
+// else the next group): the kernel is 4.7 k instructions as it is.
+template <bool IS, bool SORT, bool COUNT, bool MULTI>
 DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads,
                          unsigned long long* __restrict__ totals, int first, uint32_t resv) {
   reset_heads(heads);
-  constexpr uint32_t kRing = 128, kWaves = kBlock / 64;
+  constexpr uint32_t kRing = 128, kWaves = kBlock / 64, kBins = 3;
   static_assert((size_t)kWaves * kRing == (size_t)kSChunk, "the rings take the LDS the block version's staging arrays take");
+  static_assert(BIN_LAMBERTIAN == 0 && BIN_MIRROR == 1 && BIN_GLASS == 2, "the binned classes are material types 0..2");
   __shared__ float4 s_q0[kWaves * kRing], s_q1[kWaves * kRing], s_q2[kWaves * kRing];
+  __shared__ uint32_t s_bin[SORT ? kWaves * kBins * kRing : 1];
   constexpr uint32_t kR0Empty = 0xffffffffu, kR0Busy = 0xfffffffeu, kR0Full = 0xfffffffdu;
   __shared__ uint32_t s_region0;  // the waves' first regions: one claim per block (see shade_body)
   if (threadIdx.x == 0) s_region0 = kR0Empty;
@@ -1115,36 +1129,91 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
     head = (head + take) & (kRing - 1u);
     cnt -= take;
   };
-  for (uint32_t base = blockIdx.x * (uint32_t)kSChunk; base < n; base += gridDim.x * (uint32_t)kSChunk) {
-    const uint32_t m = min((uint32_t)kSChunk, n - base);
+  // ray_color's loop body for the slots of the lanes with `active`; survivors go into the ring, a flush pass runs whenever 64 wait
+  auto shade_slots = [&](bool active, uint32_t slot) {
+    bool survive = false, valid = false;
+    NewState ns;  // (zeroed although only the survivors' values are read: left undefined, the allocator needs 8 registers more — scratch at 80 VGPRs)
+    ns.o = ns.d = ns.T = mk3(0, 0, 0);
+    ns.bounce = 0, ns.rng = 0, ns.pid = 0;
+    if (active) {
+      LT(LT_GROUP);
+      const SlotState st = load_slot(P, slot, first != 0, rc);
+      valid = __float_as_uint(st.q1.w) != PID_HOLE;
+      if (valid) {
+        LT(LT_VALID);
+        const TriFetch tf = tri_fetch(S, P.uv, st.slot, __float_as_uint(st.tp.y));  // (issued ahead of the material's loads, consumed after them)
+        survive = shade_one<IS, MULTI>(S, rc, P, st, tf, L, ns);
+      }
+    }
+    my_valid += (uint32_t)__popcll(__ballot(valid));
+    const uint64_t mk = __ballot(survive);
+    if (survive) {
+      LT(LT_STAGE);
+      const uint32_t q = (head + cnt + lanes_below(mk)) & (kRing - 1u);
+      r0[q] = make_float4(ns.o.x, ns.o.y, ns.o.z, __uint_as_float(ns.rng));
+      r1[q] = make_float4(ns.d.x, ns.d.y, ns.d.z, __uint_as_float(ns.pid));
+      r2[q] = make_float4(ns.T.x, ns.T.y, ns.T.z, __int_as_float(ns.bounce));
+    }
+    cnt += (uint32_t)__popcll(mk);
+    if (cnt >= 64u) flush_pass(64u);
+  };
+  if (!SORT) {
+    for (uint32_t base = blockIdx.x * (uint32_t)kSChunk; base < n; base += gridDim.x * (uint32_t)kSChunk) {
+      const uint32_t m = min((uint32_t)kSChunk, n - base);
 #pragma unroll 1
-    for (uint32_t j0 = wv * 64u; j0 < m; j0 += kBlock) {
-      const uint32_t j = j0 + (uint32_t)lane;
-      bool survive = false, valid = false;
-      NewState ns;  // (zeroed although only the survivors' values are read: left undefined, the allocator needs 8 registers more — scratch at 80 VGPRs)
-      ns.o = ns.d = ns.T = mk3(0, 0, 0);
-      ns.bounce = 0, ns.rng = 0, ns.pid = 0;
-      if (j < m && !dead_slot(base + j, n_carried, resv)) {
-        LT(LT_GROUP);
-        const SlotState st = load_slot(P, base + j, first != 0, rc);
-        valid = __float_as_uint(st.q1.w) != PID_HOLE;
-        if (valid) {
-          LT(LT_VALID);
-          const TriFetch tf = tri_fetch(S, P.uv, st.slot, __float_as_uint(st.tp.y));  // (issued ahead of the material's loads, consumed after them)
-          survive = shade_one<IS, MULTI>(S, rc, P, st, tf, L, ns);
+      for (uint32_t j0 = wv * 64u; j0 < m; j0 += kBlock) {
+        const uint32_t j = j0 + (uint32_t)lane;
+        shade_slots(j < m && !dead_slot(base + j, n_carried, resv), base + j);
+      }
+    }
+  } else {
+    uint32_t* const bins = s_bin + wv * kBins * kRing;
+    uint32_t bcnt = 0, bhead = 0;  // the three bins' counts and ring heads, a byte each (wave-uniform)
+    uint32_t base = blockIdx.x * (uint32_t)kSChunk, j0 = wv * 64u;  // the next group: slots base + j0 .. + 63
+    bool final = false;
+#pragma unroll 1
+    for (;;) {
+      bool active = false;
+      uint32_t slot = 0;
+      int b = -1;  // a class with a full pass waiting (any waiting slot once the groups are used up)
+#pragma unroll
+      for (int k = (int)kBins - 1; k >= 0; k--)
+        if (((bcnt >> (8 * k)) & 0xffu) >= (final ? 1u : 64u)) b = k;
+      if (b >= 0) {
+        const uint32_t c = (bcnt >> (8 * b)) & 0xffu, h = (bhead >> (8 * b)) & 0xffu, take = min(c, 64u);
+        active = (uint32_t)lane < take;
+        if (active) slot = bins[(uint32_t)b * kRing + ((h + (uint32_t)lane) & (kRing - 1u))];
+        bcnt -= take << (8 * b);
+        bhead = (bhead & ~(0xffu << (8 * b))) | (((h + take) & (kRing - 1u)) << (8 * b));
+      } else if (!final) {
+        while (base < n && j0 >= min((uint32_t)kSChunk, n - base)) {  // this wave's groups of the block's current chunk are used up
+          base += gridDim.x * (uint32_t)kSChunk;
+          j0 = wv * 64u;
         }
+        if (base >= n) {
+          final = true;
+          continue;
+        }
+        slot = base + j0 + (uint32_t)lane;
+        j0 += kBlock;
+        int bin = 7;  // 7 = nothing here (hole, dead slot, beyond the chunk)
+        if (slot - base < min((uint32_t)kSChunk, n - base) && !dead_slot(slot, n_carried, resv)) bin = (int)((P.hin.mat[slot] >> HITMAT_BIN_SHIFT) & 7u);
+        if (bin == BIN_MISS) bin = BIN_LAMBERTIAN;  // a miss is a few instructions at the head of shade_one: it rides along with the most common class instead of costing a pass (and a memory round trip) of its own
+#pragma unroll
+        for (int k = 0; k < (int)kBins; k++) {
+          const uint64_t bm = __ballot(bin == k);
+          if (bm) {
+            const uint32_t c = (bcnt >> (8 * k)) & 0xffu, h = (bhead >> (8 * k)) & 0xffu;
+            if (bin == k) bins[(uint32_t)k * kRing + ((h + c + lanes_below(bm)) & (kRing - 1u))] = slot;
+            bcnt += (uint32_t)__popcll(bm) << (8 * k);
+          }
+        }
+        active = bin >= (int)kBins && bin < 7;  // the rare classes (isotropic media, unknown material types): with the group
+        if (__ballot(active) == 0ull) continue;
+      } else {
+        break;
       }
-      my_valid += (uint32_t)__popcll(__ballot(valid));
-      const uint64_t mk = __ballot(survive);
-      if (survive) {
-        LT(LT_STAGE);
-        const uint32_t q = (head + cnt + lanes_below(mk)) & (kRing - 1u);
-        r0[q] = make_float4(ns.o.x, ns.o.y, ns.o.z, __uint_as_float(ns.rng));
-        r1[q] = make_float4(ns.d.x, ns.d.y, ns.d.z, __uint_as_float(ns.pid));
-        r2[q] = make_float4(ns.T.x, ns.T.y, ns.T.z, __int_as_float(ns.bounce));
-      }
-      cnt += (uint32_t)__popcll(mk);
-      if (cnt >= 64u) flush_pass(64u);
+      shade_slots(active, slot);
     }
   }
   if (cnt) flush_pass(cnt);
@@ -1170,14 +1239,14 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
 template <bool IS, bool SORT, bool COUNT, bool MULTI>
 __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads,
                                                                   unsigned long long* __restrict__ totals, int first, uint32_t resv) {
-  if (SORT || PTMI_SHADE_WAVE == 0) shade_body<IS, SORT, COUNT, MULTI>(S, rc, P, ctl, heads, totals, first, resv);
-  else shade_body_wave<IS, COUNT, MULTI>(S, rc, P, ctl, heads, totals, first, resv);
+  if constexpr (PTMI_SHADE_WAVE == 0 || (SORT && PTMI_SHADE_SORT_WAVE == 0)) shade_body<IS, SORT, COUNT, MULTI>(S, rc, P, ctl, heads, totals, first, resv);
+  else shade_body_wave<IS, SORT, COUNT, MULTI>(S, rc, P, ctl, heads, totals, first, resv);
 }
 template <bool SORT, bool COUNT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_shade6(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl,
                                                                                                 uint32_t* __restrict__ heads, unsigned long long* __restrict__ totals, int first, uint32_t resv) {
-  if (SORT || PTMI_SHADE_WAVE == 0) shade_body<false, SORT, COUNT, false>(S, rc, P, ctl, heads, totals, first, resv);
-  else shade_body_wave<false, COUNT, false>(S, rc, P, ctl, heads, totals, first, resv);
+  if constexpr (PTMI_SHADE_WAVE == 0 || (SORT && PTMI_SHADE_SORT_WAVE == 0)) shade_body<false, SORT, COUNT, false>(S, rc, P, ctl, heads, totals, first, resv);
+  else shade_body_wave<false, SORT, COUNT, false>(S, rc, P, ctl, heads, totals, first, resv);
 }
 
 // k_tail — a SHORT queue traced to the end in one launch: every lane takes a path and runs ray_color's loop for it (hitScene part 2 on
