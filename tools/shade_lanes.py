@@ -51,7 +51,17 @@ def run(workload="c2", spp=0):
     ctx.clear(); ctx.render(wl["view"], 1, spp); ctx.synchronize()
     assert lib.ptmi_lane_tally(ctx.h, buf, len(POINTS), 1) == 0
     st = ctx.stats()
-    out = {"workload": wl["label"], "spp": spp, "rays": st["rays"], "paths": st["paths"], "shade_launches": st["shade_launches"],
+    TT = ["OTHER", "LOAD1_slot_state", "LOAD2_material_and_hit_data", "SHADE_compute", "STAGE", "FLUSH_PRIMS_quads_root_box", "FLUSH_STORE", "RING_READ"]
+    tb = (ctypes.c_uint64 * len(TT))()
+    times = None
+    if hasattr(lib, "ptmi_time_tally"):
+        lib.ptmi_time_tally.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        assert lib.ptmi_time_tally(ctx.h, tb, len(TT), 1) == 0
+        tot = float(sum(tb)) or 1.0
+        times = {TT[k]: {"wave_cycles": int(tb[k]), "share": tb[k] / tot} for k in range(len(TT))}
+        for k, v in times.items():
+            print("wave-cycles %-28s %5.1f %%" % (k, 100 * v["share"]))
+    out = {"workload": wl["label"], "spp": spp, "rays": st["rays"], "paths": st["paths"], "shade_launches": st["shade_launches"], "wave_cycles_by_region": times,
            "points": {POINTS[k]: {"visits": int(buf[2 * k]), "lanes": int(buf[2 * k + 1])} for k in range(len(POINTS))}}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     p = os.path.join(ROOT, "gpurun_out", "shade_lanes_%s.json" % workload)

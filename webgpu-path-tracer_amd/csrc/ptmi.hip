@@ -2067,11 +2067,23 @@ int ptmi_lane_tally(ptmi_ctx* c, uint64_t* out, int n_points, int reset) {
   }
   return PTMI_OK;
 }
+// wave-cycles per region of k_shade since the last reset (TT() marks, ptmi_device.h)
+int ptmi_time_tally(ptmi_ctx* c, uint64_t* out, int n_regions, int reset) {
+  if (!c || !out || n_regions < 0 || n_regions > kTimeTallies) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_time_tally: bad argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_time_tally), (size_t)n_regions * 8));
+  if (reset) {
+    static const unsigned long long zeros[2 * kTimeTallies] = {0};
+    HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_time_tally), zeros, sizeof zeros));
+  }
+  return PTMI_OK;
+}
 #endif
 
 int ptmi_selftest(ptmi_ctx* c, int which, uint64_t* mismatches, uint32_t* first_bad_bits) {
   if (!c || !mismatches) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_selftest: null argument");
-  if (which < 0 || which > 4) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_selftest: unknown test id");
+  if (which < 0 || which > 7) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_selftest: unknown test id");
   HIP_TRY(c, hipSetDevice(c->device));
   DBuf d;
   HIP_TRY(c, d.ensure(16));

@@ -35,9 +35,30 @@ DEV void lane_tally() {
   }
 }
 #define LT(k) lane_tally<k>()
+// ... and a stopwatch per wave: TT(k, dep) closes the interval that began at the previous mark and charges it to region k; `dep` is a value the mark must wait
+// for (the asm takes it as an operand, so the compiler puts the s_waitcnt for its load in front of the clock read).  Where do a wave's cycles go?
+constexpr int kTimeTallies = 12;
+__shared__ unsigned long long s_time_tally[4 * kTimeTallies];  // per wave of the block: cycles per region
+__shared__ unsigned long long s_time_last[4];
+__device__ unsigned long long g_time_tally[2 * kTimeTallies];  // {cycles, marks} per region
+template <int K>
+DEV void time_tally(float dep) {
+  unsigned long long now;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now) : "v"(dep) : "memory");
+  const unsigned long long m = __ballot(1);
+  if (__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0u) {
+    const uint32_t wv = threadIdx.x >> 6;
+    const unsigned long long last = s_time_last[wv];
+    if (last) atomicAdd(&s_time_tally[wv * kTimeTallies + K], now - last);
+    s_time_last[wv] = now;
+  }
+}
+#define TT(k, dep) time_tally<k>(dep)
 #else
 #define LT(k) ((void)0)
+#define TT(k, dep) ((void)0)
 #endif
+enum : int { TT_OTHER = 0, TT_LOAD1 = 1, TT_LOAD2 = 2, TT_SHADE = 3, TT_STAGE = 4, TT_FLUSH_PRIMS = 5, TT_FLUSH_STORE = 6, TT_RING_READ = 7 };
 // tally points
 enum : int {
   LT_GROUP = 0, LT_VALID = 1, LT_MISS = 2, LT_HIT = 3, LT_RH_SPHERE = 4, LT_RH_VOLUME = 5, LT_RH_QUAD = 6, LT_RH_TRI = 7, LT_MS_LAMBERT = 8, LT_MS_MIRROR = 9,
@@ -152,7 +173,13 @@ DEV f3 rcp3_exact_il(f3 a) {
   if (max(ex, max(ey, ez)) >= (200u << 23)) r = mk3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z);
   return r;
 }
-DEV float sqrt_exact(float x) {
+#ifndef PTMI_SQRT_VARIANT
+#define PTMI_SQRT_VARIANT 2  // 0 = round 3's (v_sqrt_f32 + the residual test of its two neighbours: 12 instructions, ~38 issue cycles), 1 / 2 = sqrt_cand A / C below
+#endif
+DEV float sqrt_cand(float x, int which);
+DEV float sqrt_exact_r3(float x);
+DEV float sqrt_exact(float x) { return PTMI_SQRT_VARIANT == 0 ? sqrt_exact_r3(x) : sqrt_cand(x, PTMI_SQRT_VARIANT == 1 ? 0 : 2); }
+DEV float sqrt_exact_r3(float x) {
   // the compiler's sequence without its scaling: s = v_sqrt(x) is within 1 ulp; its neighbours are tried against the exact residuals
   const float s = __builtin_amdgcn_sqrtf(x);
   const float dn = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
@@ -160,6 +187,26 @@ DEV float sqrt_exact(float x) {
   float r = (rd <= 0.0f) ? dn : s;
   r = (ru > 0.0f) ? up : r;
   if ((__float_as_uint(x) - (37u << 23)) >= (210u << 23)) r = sqrt_ieee_slow(x);  // x < 2^-90 (incl. 0, negative: sign bit set) or >= 2^120 (incl. inf, NaN)
+  return r;
+}
+// Shorter sequences with the IEEE bits (round 4; ptmi_selftest 5..7 run each over all 2^32 arguments on the device): one Markstein correction
+// s + (x - s*s) * h of v_sqrt_f32's result with h ~ 1/(2s) from v_rsq_f32 (A: 0 mismatches) or from v_rcp_f32 (B: 105 mismatches — not used), and the two-step
+// scheme from v_rsq_f32 alone (C: 0 mismatches; one transcendental, 7 instructions, ~20 issue cycles — the one in use).  Same guarded range as round 3's.
+DEV float sqrt_cand(float x, int which) {
+  float r;
+  if (which == 0) {
+    const float s = __builtin_amdgcn_sqrtf(x), h = 0.5f * __builtin_amdgcn_rsqf(x);
+    r = __builtin_fmaf(__builtin_fmaf(-s, s, x), h, s);
+  } else if (which == 1) {
+    const float s = __builtin_amdgcn_sqrtf(x), h = __builtin_amdgcn_rcpf(s + s);
+    r = __builtin_fmaf(__builtin_fmaf(-s, s, x), h, s);
+  } else {
+    const float g = __builtin_amdgcn_rsqf(x), h = 0.5f * g;
+    const float s0 = x * g;
+    const float s1 = __builtin_fmaf(__builtin_fmaf(-s0, s0, x), h, s0);
+    r = __builtin_fmaf(__builtin_fmaf(-s1, s1, x), h, s1);
+  }
+  if ((__float_as_uint(x) - (37u << 23)) >= (210u << 23)) r = sqrt_ieee_slow(x);
   return r;
 }
 DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }

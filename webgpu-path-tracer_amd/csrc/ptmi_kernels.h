@@ -620,6 +620,7 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
     // the chunk is sorted by this class, so `bin` is wave-uniform almost everywhere
     const int bin = (m.type == 0.0f) ? BIN_LAMBERTIAN : (m.type == 1.0f) ? BIN_MIRROR : (m.type == 2.0f) ? BIN_GLASS : (m.type == 3.0f) ? BIN_ISOTROPIC : BIN_OTHER;
     HitGeom g = resolve_hit(S, o, d, st.tp.x, tf, prim);
+    TT(TT_LOAD2, g.n.x + m.type + m.color.x);  // the material's record and the hit's normal data have arrived
     f3 emission = m.emission;
     if (!g.front) emission = mk3(0, 0, 0);  // traceRay.wgsl:19-22
     float doSpecular;
@@ -1031,6 +1032,8 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
   if (threadIdx.x == 0) s_region0 = kR0Empty;
 #ifdef PTMI_LANE_TALLY
   if (threadIdx.x < kLaneTallies * 2) s_lane_tally[threadIdx.x] = 0u;
+  if (threadIdx.x < 4 * kTimeTallies) s_time_tally[threadIdx.x] = 0ull;
+  if (threadIdx.x < 4) s_time_last[threadIdx.x] = 0ull;
 #endif
   __syncthreads();
   const QuadL L = load_light(S);
@@ -1055,8 +1058,10 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
     if ((uint32_t)lane < take) {
       LT(LT_FLUSH);
       const float4 a0 = r0[q], a1 = r1[q];
+      TT(TT_RING_READ, a0.x + a1.x);
       rng = __float_as_uint(a0.w);
       prims_for_ray<COUNT>(S, mk3(a0), mk3(a1), rng, tp, hm, cn);
+      TT(TT_FLUSH_PRIMS, tp.x + __uint_as_float(hm));
       if (kMissShortcut && !MULTI && hm == HITMAT_MISS) {  // traceRay.wgsl:12-16 (see shade_body)
         LT(LT_MISS_SHORTCUT);
         const float4 a2 = r2[q];
@@ -1128,6 +1133,7 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
     }
     head = (head + take) & (kRing - 1u);
     cnt -= take;
+    TT(TT_FLUSH_STORE, 0.0f);
   };
   // ray_color's loop body for the slots of the lanes with `active`; survivors go into the ring, a flush pass runs whenever 64 wait
   auto shade_slots = [&](bool active, uint32_t slot) {
@@ -1135,9 +1141,11 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
     NewState ns;  // (zeroed although only the survivors' values are read: left undefined, the allocator needs 8 registers more — scratch at 80 VGPRs)
     ns.o = ns.d = ns.T = mk3(0, 0, 0);
     ns.bounce = 0, ns.rng = 0, ns.pid = 0;
+    TT(TT_OTHER, 0.0f);  // (what came before this group: loop bookkeeping, the previous flush's tail)
     if (active) {
       LT(LT_GROUP);
       const SlotState st = load_slot(P, slot, first != 0, rc);
+      TT(TT_LOAD1, st.q0.x + st.q1.x + st.q2.x + st.tp.x + __uint_as_float(st.hitmat));  // the slot's state has arrived
       valid = __float_as_uint(st.q1.w) != PID_HOLE;
       if (valid) {
         LT(LT_VALID);
@@ -1145,6 +1153,7 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
         survive = shade_one<IS, MULTI>(S, rc, P, st, tf, L, ns);
       }
     }
+    TT(TT_SHADE, ns.o.x + ns.T.x);  // material + hit geometry fetched (TT_LOAD2, marked inside shade_one) and the bounce computed
     my_valid += (uint32_t)__popcll(__ballot(valid));
     const uint64_t mk = __ballot(survive);
     if (survive) {
@@ -1155,6 +1164,7 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
       r2[q] = make_float4(ns.T.x, ns.T.y, ns.T.z, __int_as_float(ns.bounce));
     }
     cnt += (uint32_t)__popcll(mk);
+    TT(TT_STAGE, 0.0f);
     if (cnt >= 64u) flush_pass(64u);
   };
   if (!SORT) {
@@ -1222,6 +1232,11 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
   __syncthreads();  // the block's claim, if any wave made one, is in s_region0 now
 #ifdef PTMI_LANE_TALLY
   if (threadIdx.x < kLaneTallies * 2 && s_lane_tally[threadIdx.x]) atomicAdd(&g_lane_tally[threadIdx.x], (unsigned long long)s_lane_tally[threadIdx.x]);
+  if (threadIdx.x < kTimeTallies) {
+    unsigned long long t = 0;
+    for (int w = 0; w < 4; w++) t += s_time_tally[w * kTimeTallies + threadIdx.x];
+    if (t) atomicAdd(&g_time_tally[threadIdx.x], t);
+  }
 #endif
   if (w_rend == 0u && s_region0 < kR0Full) {  // never needed a region: all of this wave's quarter of the block's claim becomes holes
     w_cur = s_region0 + wv * wregion;
@@ -1577,6 +1592,7 @@ __global__ __launch_bounds__(256) void k_selftest(int which, unsigned long long*
     else if (which == 1) ok = same(sqrt_exact(x), sqrt_ieee_slow(x));
     else if (which == 3) ok = same(__builtin_amdgcn_rcpf(x), rcp_ieee_slow(x));   // the harness itself: the raw 1-ulp instructions must NOT pass
     else if (which == 4) ok = same(__builtin_amdgcn_sqrtf(x), sqrt_ieee_slow(x));
+    else if (which >= 5 && which <= 7) ok = same(sqrt_cand(x, which - 5), sqrt_ieee_slow(x));  // candidates (ptmi_device.h), not in use unless one passes
     else {
       const float want = rcp_ieee_slow(x);
       const f3 a = rcp3_exact(mk3(x, 3.0f, -0.7f)), b = rcp3_exact_il(mk3(1.5f, x, 1e-3f)), c = rcp3_exact(mk3(-2.0f, 1e6f, x)), d = rcp3_exact_il(mk3(x, x, x));
