@@ -108,3 +108,6 @@ def test_exhaustive_reciprocal_and_sqrt_shortcuts(ctx):
         bad, first = ctx.selftest(which)
         assert bad == 0, "%s differs from the IEEE operation for %d arguments, first 0x%08x" % (name, bad, first)
     assert ctx.selftest(3)[0] > 10 ** 8 and ctx.selftest(4)[0] > 10 ** 8  # v_rcp_f32 / v_sqrt_f32 alone are 1-ulp approximations
+    # round 4: sqrt_exact is the two-step Markstein scheme from v_rsq_f32 (candidate C = id 7, what id 1 now runs); candidate A (v_sqrt_f32 + one correction
+    # with v_rsq_f32 / 2) is exact too, candidate B (the correction's 1 / 2s from v_rcp_f32) is not — which is why it is not the one in use
+    assert ctx.selftest(5)[0] == 0 and ctx.selftest(7)[0] == 0 and 0 < ctx.selftest(6)[0] < 10 ** 4

@@ -1,14 +1,16 @@
 #!/bin/bash
-# Runs on the GPU box (through gpurun): parity tests, smoke, the bench line as the driver runs it (with its own rocprofv3 --pmc passes),
-# the other workloads, rocprofv3 kernel stats of the bench command, the VALU issue microbenchmark.  Everything lands in gpurun_out/rel/;
-# tools/collect_profiles.py files it under profiles/.   usage: tools/release_pass.sh [quick]
+# Runs on the GPU box (through gpurun): parity tests, smoke, the bench line as the driver runs it (with its own rocprofv3 --pmc passes), the other
+# workloads, rocprofv3 kernel stats of the bench command, the microbenchmarks the rooflines rest on, round 4's measurements (lane / stopwatch tallies of
+# k_shade, rocprof's VALUBusy on single-opcode kernels, one rank of 1 / 2 / 4 / 8, the OBJ parser against the reference's reader).  Everything lands in
+# gpurun_out/rel/; tools/collect_profiles.py rNN files it under profiles/.   usage: tools/release_pass.sh [quick | extras]
 set -o pipefail
 R=gpurun_out/rel; mkdir -p $R; export TMPDIR=/tmp
 root=$(pwd)
-if [ "$1" != quick ]; then
+if [ "$1" != quick ] && [ "$1" != extras ]; then
   timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 | tee $R/pytest_gpu.txt || exit 1
   timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $R/smoke.txt || exit 1
 fi
+if [ "$1" != extras ]; then
 SECONDS=0
 timeout -k 10 600 python bench.py --steps 20 --warmup 5 > $R/bench_c2.json 2> $R/bench_c2.err || exit 1
 echo "bench.py --steps 20 --warmup 5: wall ${SECONDS} s" | tee $R/bench_c2_wall.txt
@@ -22,10 +24,17 @@ for w in c2 c3 c4 c5; do
   (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$w -o run -- python3 $root/bench.py --workload $w $x --steps 3 --warmup 1 --cpu-seconds 0 --pmc off --extra-configs off > $root/$R/ks_$w.log 2>&1) || exit 1
   cp $(find /tmp/ks_$w -name '*kernel_stats.csv' | head -1) $R/kernel_stats_$w.csv || exit 1
 done
+fi
+if [ "$1" != quick ]; then
 [ -x tools/valu_peak ] && timeout -k 10 300 tools/valu_peak > $R/valu_peak.json 2> $R/valu_peak.err
+bash tools/valu_busy_calib.sh > $R/valu_busy_calib.txt 2>&1 && cp gpurun_out/valu_busy_calib.json $R/
 # the gather path's ceiling (k_bvh's roofline) and the sweeps that show k_bvh sits on it
 [ -x tools/gather_probe ] && timeout -k 10 300 tools/gather_probe > $R/gather_probe.json 2> $R/gather_probe.err
-[ -x tools/gather_probe2 ] && timeout -k 10 300 tools/gather_probe2 > $R/gather_probe2.json 2> $R/gather_probe2.err
-bash tools/r3_size.sh > /dev/null 2>&1; cp gpurun_out/r3ab/size_sweep.txt $R/ 2>/dev/null
-bash tools/r3_coh.sh > /dev/null 2>&1; cp gpurun_out/r3ab/coherence.txt $R/ 2>/dev/null
+bash tools/sweep.sh size > /dev/null 2>&1; cp gpurun_out/sweep/size_sweep.txt $R/ 2>/dev/null
+timeout -k 10 400 python tools/shard_sim.py c2 c3 > $R/shard_sim.txt 2>&1 && cp gpurun_out/shard_sim.json $R/
+timeout -k 10 400 python tools/obj_parse_bench.py > $R/obj_parse.json 2> $R/obj_parse.err
+if [ -f webgpu-path-tracer_amd/variants/libptmi_lanes.so ]; then
+  for w in c2 c3 c5; do timeout -k 10 200 python tools/shade_lanes.py run $w > $R/shade_lanes_$w.txt 2>&1 && cp gpurun_out/shade_lanes_$w.json $R/; done
+fi
+fi
 echo release pass done
