@@ -630,8 +630,8 @@ def main():
             tab["k_bvh"]["records_per_launch"] = gather
         # What SURVEY §8d's yardstick calls waste: HBM bytes the step moves beyond what the reference's megakernel must move — its framebuffer read-modify-write
         # once per frame (32 B per pixel and frame) and the scene once.  The wavefront design pays the rest as path state crossing HBM between kernels.
-        if all(tab[k].get("hbm_bytes_per_launch") is not None for k in KERNELS):
-            step_bytes = sum(tab[k]["hbm_bytes_per_launch"] * tab[k]["launches_per_step"] for k in KERNELS)
+        if any(tab[k].get("hbm_bytes_per_launch") is not None for k in KERNELS):  # (a kernel the batch never launched has no counters and moved nothing)
+            step_bytes = sum((tab[k].get("hbm_bytes_per_launch") or 0.0) * tab[k]["launches_per_step"] for k in KERNELS)
             scene_bytes = sum(np.asarray(wl["buffers"][k]).nbytes for k in ("spheres", "quads", "triangles", "meshes", "transforms", "materials", "bvh"))
             compulsory = 32.0 * wl["W"] * wl["H"] * spp / max(world, 1) + scene_bytes
             roof["step_hbm_bytes"] = step_bytes
