@@ -124,7 +124,8 @@ struct Tuning {
   int waves_per_cu = 0;        // PTMI_WAVES_PER_CU: k_bvh's grid (0 = auto)
   int bvh_teams = 16;          // PTMI_BVH_TEAMS: claim counters of k_bvh
   int refill = kRefillThreshold, leaf_batch = kLeafBatch, bvh_range = (int)kBvhRange;  // PTMI_REFILL, PTMI_LEAF_BATCH, PTMI_BVH_RANGE
-  int tail_waves_per_cu = 16;  // PTMI_TAIL_WAVES_PER_CU
+  int tail_waves_per_cu = 0;   // PTMI_TAIL_WAVES_PER_CU (0 = 16, or 24 for the 6-wave build)
+  bool tail6 = true;           // PTMI_TAIL6=0: never the 80-VGPR build of k_tail
   int bvh_carry = 32;          // PTMI_BVH_CARRY: iterations a k_bvh wave goes on after the queue is exhausted before it carries its unfinished rays into the next
                                // step's queue (Carry, ptmi_device.h); 0 = never (every launch traces its longest ray to the end)
   int bvh_carry_slots = 1 << 18;  // PTMI_BVH_CARRY_SLOTS: the queues' carry prefix
@@ -734,7 +735,8 @@ void load_tuning(ptmi_ctx* c) {
   t.refill = env_int("PTMI_REFILL", t.refill);
   t.leaf_batch = env_int("PTMI_LEAF_BATCH", t.leaf_batch);
   t.bvh_range = std::max(64, std::min(1 << 16, env_int("PTMI_BVH_RANGE", t.bvh_range))) & ~63;
-  t.tail_waves_per_cu = std::max(1, std::min(32, env_int("PTMI_TAIL_WAVES_PER_CU", t.tail_waves_per_cu)));
+  t.tail_waves_per_cu = std::max(0, std::min(32, env_int("PTMI_TAIL_WAVES_PER_CU", t.tail_waves_per_cu)));
+  t.tail6 = env_int("PTMI_TAIL6", 1) != 0;
   t.bvh_carry = std::max(0, env_int("PTMI_BVH_CARRY", t.bvh_carry));
   t.bvh_carry_slots = std::max(64, std::min(1 << 22, env_int("PTMI_BVH_CARRY_SLOTS", t.bvh_carry_slots)));
   t.bvh_carry_last = std::max(0, env_int("PTMI_BVH_CARRY_LAST", t.bvh_carry_last));
@@ -861,7 +863,9 @@ int launch_tail(ptmi_ctx* c, const RenderConst& rc, const Paths& P, StepCtl* ctl
   const int se = sa - le;
   const size_t lds = (size_t)le * 2 * 64 * sizeof(int);
   const bool noabort = c->bvh_depth < c->prm.stack_size && c->tun.noabort;
-  const int waves_per_cu = c->tun.tail_waves_per_cu;
+  // progressive mode without importance sampling on a scene without spheres: the 80-VGPR build, 6 waves per SIMD (k_tail6)
+  const bool six = !c->prm.importance_sampling && rc.num_samples == 1 && c->S.n_spheres == 0 && c->tun.tail6;
+  const int waves_per_cu = c->tun.tail_waves_per_cu > 0 ? c->tun.tail_waves_per_cu : (six ? 24 : 16);
   const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)limit + 63) / 64, (uint64_t)c->num_cus * (uint64_t)waves_per_cu));
   HIP_TRY(c, c->d_spill.ensure(std::max<size_t>(16, (size_t)c->num_cus * 32 * (size_t)se * 64 * sizeof(int2))));  // (k_bvh's grids are no larger: one size for both)
   unsigned long long* tot = c->d_totals.as<unsigned long long>();
@@ -878,7 +882,18 @@ int launch_tail(ptmi_ctx* c, const RenderConst& rc, const Paths& P, StepCtl* ctl
     if (rc.num_samples > 1) PTMI_LAUNCH_TAIL3(IS, CN, true);  \
     else PTMI_LAUNCH_TAIL3(IS, CN, false);                    \
   } while (0)
-  if (c->prm.importance_sampling) {
+  if (six) {
+#define PTMI_LAUNCH_TAIL6(CN, NA) \
+  hipLaunchKernelGGL((k_tail6<CN, NA>), dim3(grid), dim3(64), lds, c->stream, c->S, rc, P, ctl, tot, first, limit, c->prm.stack_size, le, se, c->d_spill.as<int2>(), cy)
+    if (c->counters) {
+      if (noabort) PTMI_LAUNCH_TAIL6(true, true);
+      else PTMI_LAUNCH_TAIL6(true, false);
+    } else {
+      if (noabort) PTMI_LAUNCH_TAIL6(false, true);
+      else PTMI_LAUNCH_TAIL6(false, false);
+    }
+#undef PTMI_LAUNCH_TAIL6
+  } else if (c->prm.importance_sampling) {
     if (c->counters) PTMI_LAUNCH_TAIL2(true, true);
     else PTMI_LAUNCH_TAIL2(true, false);
   } else {

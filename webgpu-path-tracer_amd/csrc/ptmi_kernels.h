@@ -1272,8 +1272,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) 
 // when it has run, the block that finishes last zeroes the queue length, so the step's k_bvh / k_shade and every later step find nothing.
 // Same per-ray arithmetic and visit order as the wavefront kernels (the same device functions), same counters and tallies.
 template <bool IS, bool COUNT, bool MULTI, bool NOABORT>
-__global__ __launch_bounds__(64) void k_tail(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, unsigned long long* __restrict__ totals, int first, uint32_t limit,
-                                             int stack_size, int lds_entries, int spill_entries, int2* __restrict__ spill, Carry cy) {
+DEV void tail_body(const DevScene& S, const RenderConst& rc, const Paths& P, StepCtl* __restrict__ ctl, unsigned long long* __restrict__ totals, int first, uint32_t limit,
+                   int stack_size, int lds_entries, int spill_entries, int2* __restrict__ spill, const Carry& cy) {
   const uint32_t n_carried = cy.resv ? min(ctl->n_carried, cy.resv) : 0u;  // (Carry: slots [n_carried, resv) hold nothing, [0, n_carried) rays whose traversal goes on)
   const uint32_t n = ctl->n_rays;
   if (n <= cy.resv && n_carried == 0u) return;            // empty
@@ -1418,6 +1418,22 @@ __global__ __launch_bounds__(64) void k_tail(DevScene S, RenderConst rc, Paths P
       ctl->n_carried = 0u;
     }
   }
+}
+
+// The kernel proper, twice (like k_shade / k_shade6): in progressive mode without importance sampling, on scenes WITHOUT spheres, the body fits 80 VGPRs with 16
+// bytes of scratch — 6 waves per SIMD instead of 4: a lone 1080p frame of configs[1] 0.84 -> 0.74 ms, of the 871 k-triangle scene 3.4 -> 3.1 (round 4,
+// profiles/r04_tail_occupancy.txt); with spheres and fog volumes in the scene (the reference's default) the same build spills in their code and loses 8 %, so
+// those scenes, importance sampling and NUM_SAMPLES > 1 keep the compiler's own allocation (100-130 VGPRs, 4 waves).
+template <bool IS, bool COUNT, bool MULTI, bool NOABORT>
+__global__ __launch_bounds__(64) void k_tail(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, unsigned long long* __restrict__ totals, int first, uint32_t limit,
+                                             int stack_size, int lds_entries, int spill_entries, int2* __restrict__ spill, Carry cy) {
+  tail_body<IS, COUNT, MULTI, NOABORT>(S, rc, P, ctl, totals, first, limit, stack_size, lds_entries, spill_entries, spill, cy);
+}
+template <bool COUNT, bool NOABORT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_tail6(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl,
+                                                                                         unsigned long long* __restrict__ totals, int first, uint32_t limit, int stack_size,
+                                                                                         int lds_entries, int spill_entries, int2* __restrict__ spill, Carry cy) {
+  tail_body<false, COUNT, false, NOABORT>(S, rc, P, ctl, totals, first, limit, stack_size, lds_entries, spill_entries, spill, cy);
 }
 
 // A batch's step records: every queue but step 0's starts behind its carry prefix (Carry)
