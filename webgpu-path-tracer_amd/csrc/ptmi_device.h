@@ -1091,12 +1091,6 @@ DEV f3 material_scatter(int bin, const Material& m, const HitGeom& g, f3 din, ui
   skip_pdf = true;
   if (bin == BIN_LAMBERTIAN) {
     LT(LT_MS_LAMBERT);
-#ifdef PTMI_PROBE_NO_SCATTER  // timing probe only (wrong images): what does k_shade cost without the Lambertian bounce's arithmetic?
-    unit_w = g.n;
-    doSpecular = (rand2D(rng) < m.specularStrength) ? 1.0f : 0.0f;
-    skip_pdf = false;
-    return reflect3(din, g.n);
-#endif
     Onb b = onb_build_from_w(g.n);
     unit_w = b.w;
     f3 diffuse = cosine_sampling_wrt_Z(rng);
