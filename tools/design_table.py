@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Regenerates the results table of DESIGN.md §5 (between the r03-table markers) from profiles/rNN_*_bench.json.  usage: tools/design_table.py [r03]"""
+"""Regenerates the results table of DESIGN.md §5 (between the rNN-table markers) from profiles/rNN_*_bench.json.  usage: tools/design_table.py [r04]"""
 import json
 import os
 import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 D = {w: json.load(open(os.path.join(ROOT, "profiles", "%s_%s_bench.json" % (tag, w)))) for w in ("c2", "c3", "c4", "c5")}
 cols = ["c2", "c3", "c4", "c5"]
 
@@ -27,17 +27,18 @@ spp = {"c2": "64 spp", "c3": "256 spp", "c4": "512 spp", "c5": "128 spp"}
 rows.append("| ms per step | " + " | ".join("%.1f (%s)" % (D[w]["ms_per_step"], spp[w]) for w in cols) + " |")
 rows.append("| node visits / triangle tests per ray | " + " | ".join("%.1f / %.2f" % (D[w]["roofline"]["work_per_ray"]["node_visits"], D[w]["roofline"]["work_per_ray"]["tri_tests"]) for w in cols) + " |")
 rows.append("| ms per step: generate / bvh / shade / tail / accumulate | " + " | ".join(" / ".join(f(k(w, n)["ms_per_step"], 2 if k(w, n)["ms_per_step"] < 100 else 0) for n in ("k_generate", "k_bvh", "k_shade", "k_tail", "k_accumulate")) for w in cols) + " |")
-rows.append("| dominant kernel: bound, `frac` | " + " | ".join("`%s`: %s **%.2f**" % (D[w]["roofline"]["kernel"], {"valu_issue": "VALU issue (upper bound)", "l1_gather": "L1 gather", "hbm": "HBM"}[D[w]["roofline"]["bound"]], D[w]["roofline"]["frac"]) for w in cols) + " |")
-rows.append("| the same kernel: at 2.4 GHz / integer at 3 cycles / lane-weighted | " + " | ".join("%s / %s / %s" % (f(D[w]["roofline"].get("frac_at_2p4_ghz")), f(D[w]["roofline"].get("valu_busy_frac_int_at_3")), f(D[w]["roofline"].get("lane_weighted_frac"))) for w in cols) + " |")
-rows.append("| `k_bvh`: L1 gather / VALU busy (≤) / fabric bytes ÷ 8 TB/s / active lanes / waves parked on memory | " + " | ".join("%s / %s / %s / %s / %s" % (f(k(w, "k_bvh").get("l1_gather_frac")), f(k(w, "k_bvh").get("valu_busy_frac")), f(k(w, "k_bvh").get("hbm_frac")), f(k(w, "k_bvh").get("active_lane_frac")), f(k(w, "k_bvh").get("wave_wait_frac"))) for w in cols) + " |")
-rows.append("| `k_shade`: VALU busy (≤) / HBM / active lanes / waves parked | " + " | ".join("%s / %s / %s / %s" % (f(k(w, "k_shade").get("valu_busy_frac")), f(k(w, "k_shade").get("hbm_frac")), f(k(w, "k_shade").get("active_lane_frac")), f(k(w, "k_shade").get("wave_wait_frac"))) for w in cols) + " |")
-rows.append("| `k_generate`: VALU busy (≤) / at 2.4 GHz / HBM | " + " | ".join("%s / %s / %s" % (f(k(w, "k_generate").get("valu_busy_frac")), f(k(w, "k_generate").get("valu_busy_frac_at_2p4_ghz")), f(k(w, "k_generate").get("hbm_frac"))) for w in cols) + " |")
+rows.append("| dominant kernel: bound, `frac` | " + " | ".join("`%s`: %s **%.2f**" % (D[w]["roofline"]["kernel"], {"valu_issue": "VALU issue at 2.4 GHz", "l1_gather": "L1 gather at 2.4 GHz", "hbm": "HBM"}[D[w]["roofline"]["bound"]], D[w]["roofline"]["frac"]) for w in cols) + " |")
+rows.append("| the same kernel: VALU model at the pass clock / all-unclassified-at-4 upper bound / rocprof VALUBusy / lane-weighted at 2.4 GHz | " + " | ".join("%s / %s / %s / %s" % (f(D[w]["roofline"].get("valu_busy_frac_at_pass_clock")), f(D[w]["roofline"].get("valu_busy_frac_upper_bound_at_pass_clock")), f(D[w]["roofline"].get("rocprof_valu_busy")), f(D[w]["roofline"].get("lane_weighted_frac_at_2p4_ghz"))) for w in cols) + " |")
+rows.append("| `k_bvh`: L1 gather / VALU at 2.4 GHz / fabric bytes ÷ 8 TB/s / active lanes / waves parked on memory | " + " | ".join("%s / %s / %s / %s / %s" % (f(k(w, "k_bvh").get("l1_gather_frac")), f(k(w, "k_bvh").get("valu_busy_frac_at_2p4_ghz")), f(k(w, "k_bvh").get("hbm_frac")), f(k(w, "k_bvh").get("active_lane_frac")), f(k(w, "k_bvh").get("wave_wait_frac"))) for w in cols) + " |")
+rows.append("| `k_shade`: VALU at 2.4 GHz / rocprof VALUBusy / HBM / active lanes / waves parked | " + " | ".join("%s / %s / %s / %s / %s" % (f(k(w, "k_shade").get("valu_busy_frac_at_2p4_ghz")), f(k(w, "k_shade").get("rocprof_valu_busy")), f(k(w, "k_shade").get("hbm_frac")), f(k(w, "k_shade").get("active_lane_frac")), f(k(w, "k_shade").get("wave_wait_frac"))) for w in cols) + " |")
+rows.append("| `k_generate`: VALU at 2.4 GHz / at the pass clock / rocprof VALUBusy / HBM | " + " | ".join("%s / %s / %s / %s" % (f(k(w, "k_generate").get("valu_busy_frac_at_2p4_ghz")), f(k(w, "k_generate").get("valu_busy_frac_at_pass_clock")), f(k(w, "k_generate").get("rocprof_valu_busy")), f(k(w, "k_generate").get("hbm_frac"))) for w in cols) + " |")
+rows.append("| one step over the fabric: GB / ÷ 8 TB/s / × the reference megakernel's compulsory bytes | " + " | ".join("%.1f / %s / %.1f×" % (D[w]["roofline"]["step_hbm_bytes"] / 1e9, f(D[w]["roofline"].get("step_hbm_frac")), D[w]["roofline"]["step_hbm_bytes"] / D[w]["roofline"]["compulsory_bytes"]) if D[w]["roofline"].get("step_hbm_bytes") else "—" for w in cols) + " |")
 rows.append("| CPU oracle, 16 threads / 1 thread (Mrays/s) | " + " | ".join("%.1f / %.1f" % (D[w]["cpu_baseline"]["value"], D[w]["cpu_baseline"]["single_thread"]["value"]) for w in cols) + " |")
 rows.append("| vs. 33.5 Mpaths/s (`benchmarks.txt:18-20`): paths / rays | " + " | ".join("%.0f× / %.0f×" % (D[w]["config"]["mpaths_per_s"] / 33.5, D[w]["value"] / 33.5) for w in cols) + " |")
 table = "\n".join("  " + r for r in rows)
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
-begin, end = "  <!-- r03-table-begin -->\n", "  <!-- r03-table-end -->"
+begin, end = "  <!-- %s-table-begin -->\n" % tag, "  <!-- %s-table-end -->" % tag
 i, j = s.find(begin), s.find(end)
 n = 1 if (i >= 0 and j > i) else 0
 s2 = s[: i + len(begin)] + table + "\n" + s[j:] if n else s
