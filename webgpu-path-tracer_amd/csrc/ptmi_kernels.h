@@ -1453,14 +1453,33 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(RenderConst rc, Paths P, 
     uint32_t pix = local_to_pixel(rc, j);
     float4 cur = fb[pix];
     f3 c = mk3(cur);
-    for (int f = f_begin; f < f_end; f++) {
-      const size_t pid = (size_t)f * rc.n_local + j;
-      f3 col = mk3(0, 0, 0);  // a path that never wrote its acc_radiance returned (0,0,0)
-      if (!P.touched || P.touched[pid]) col = mk3(P.acc[pid]);
-      if (f == 0 && rc.reset_first) {
-        c = col;
-      } else {
-        c = c + col;
+    // The frames are added in frame order (the f32 sum is the reference's), but their colours are FETCHED eight at a time: a pixel's thread used to walk
+    // flag -> colour -> add one frame after the other, two dependent round trips per frame — with pixel tiles sharded over 8 GPUs that is 512 frames per
+    // thread and an eighth of the threads (tools/shard_sim.py).
+    constexpr int kAhead = 8;
+    for (int f0 = f_begin; f0 < f_end; f0 += kAhead) {
+      bool have[kAhead];
+      float4 colv[kAhead];
+#pragma unroll
+      for (int k = 0; k < kAhead; k++) {
+        const int f = f0 + k;
+        have[k] = f < f_end && (!P.touched || P.touched[(size_t)f * rc.n_local + j]);
+      }
+#pragma unroll
+      for (int k = 0; k < kAhead; k++) {
+        colv[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // a path that never wrote its acc_radiance returned (0,0,0)
+        if (have[k]) colv[k] = P.acc[(size_t)(f0 + k) * rc.n_local + j];
+      }
+#pragma unroll
+      for (int k = 0; k < kAhead; k++) {
+        const int f = f0 + k;
+        if (f >= f_end) break;
+        const f3 col = mk3(colv[k]);
+        if (f == 0 && rc.reset_first) {
+          c = col;
+        } else {
+          c = c + col;
+        }
       }
     }
     fb[pix] = make_float4(c.x, c.y, c.z, 1.0f);
