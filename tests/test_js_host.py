@@ -34,7 +34,7 @@ def test_addon_loads_and_exports_surface(pkg):
     out = _run([node, "-e", "const p=require('./ptmi.node');console.log(JSON.stringify({v:p.version(),k:Object.keys(p).sort(),buf:p.BUF,d:p.defaultParams()}))"], cwd=JS)
     o = json.loads(out)
     assert o["v"] == 4
-    assert set(o["k"]) >= {"create", "prepare", "destroy", "upload", "resize", "renderFrame", "render", "readFramebuffer", "stats", "buildBVH", "buildBVHSAH", "buildBVHDevice", "parseObj", "setParams", "resolveRGBA8"}
+    assert set(o["k"]) >= {"create", "prepare", "destroy", "upload", "resize", "renderFrame", "render", "readFramebuffer", "stats", "buildBVH", "buildBVHSAH", "buildBVHDevice", "parseObj", "setParams", "resolveRGBA8", "deviceCount", "reduceInfo"}
     assert o["buf"] == pkg.ptmi.BUF
     assert o["d"]["max_bounces"] == 100 and o["d"]["stack_size"] == 20 and o["d"]["background"] == [0, 1, 1]
     assert abs(o["d"]["tmin"] - 1e-6) < 1e-12 and abs(o["d"]["light_mix"] - 0.2) < 1e-7

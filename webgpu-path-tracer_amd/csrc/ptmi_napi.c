@@ -50,6 +50,8 @@ FN(ptmi_build_bvh_device)
 FN(ptmi_build_scene_bvh)
 FN(ptmi_obj_parse)
 FN(ptmi_free)
+FN(ptmi_device_count)
+FN(ptmi_reduce_info)
 
 static int load_lib(char* err, size_t errlen) {
   if (g_lib) return 0;
@@ -83,7 +85,7 @@ static int load_lib(char* err, size_t errlen) {
   LOAD(ptmi_get_params) LOAD(ptmi_upload) LOAD(ptmi_resize) LOAD(ptmi_clear_framebuffer) LOAD(ptmi_set_shard) LOAD(ptmi_render_frame)
   LOAD(ptmi_render) LOAD(ptmi_synchronize) LOAD(ptmi_read_framebuffer) LOAD(ptmi_write_framebuffer) LOAD(ptmi_resolve_rgba8)
   LOAD(ptmi_set_counters) LOAD(ptmi_set_timing) LOAD(ptmi_get_stats) LOAD(ptmi_reset_stats) LOAD(ptmi_build_bvh) LOAD(ptmi_build_bvh_sah) LOAD(ptmi_build_bvh_device) LOAD(ptmi_build_scene_bvh)
-  LOAD(ptmi_obj_parse) LOAD(ptmi_free)
+  LOAD(ptmi_obj_parse) LOAD(ptmi_free) LOAD(ptmi_device_count) LOAD(ptmi_reduce_info)
   return 0;
 }
 
@@ -522,6 +524,24 @@ static napi_value js_reset_stats(napi_env env, napi_callback_info info) {
   return NULL;
 }
 
+/* deviceCount() -> GPUs this process sees; reduceInfo(ctx) -> one line about how a multi-device context sums its devices' buffers (RCCL, add kernel,
+ * or "FALLBACK: hipMemcpyPeer + add (<what failed>)" — API v4: an RCCL failure no longer fails the host) */
+static napi_value js_device_count(napi_env env, napi_callback_info info) {
+  (void)info;
+  napi_value v;
+  CHECK_NAPI(napi_create_int32(env, p_ptmi_device_count(), &v));
+  return v;
+}
+static napi_value js_reduce_info(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (get_args(env, info, 1, a)) return NULL;
+  ptmi_ctx* c = ctx_of(env, a[0]);
+  if (!c) return NULL;
+  napi_value v;
+  CHECK_NAPI(napi_create_string_utf8(env, p_ptmi_reduce_info(c), NAPI_AUTO_LENGTH, &v));
+  return v;
+}
+
 /* buildBVH(bmin: Float64Array(3n), bmax: Float64Array(3n), primType) -> { nodes: Float32Array, order: Int32Array } */
 static napi_value build_bvh_common(napi_env env, napi_callback_info info, int sah) { /* sah: 0 median (host), 1 SAH (host), 2 median on the GPU of ctx */
   napi_value all[4];
@@ -643,6 +663,7 @@ static napi_value init(napi_env env, napi_value exports) {
       {"render", js_render}, {"synchronize", js_synchronize}, {"prepare", js_prepare}, {"buildSceneBVH", js_build_scene_bvh}, {"readFramebuffer", js_read_fb}, {"writeFramebuffer", js_write_fb},
       {"resolveRGBA8", js_resolve}, {"setCounters", js_set_counters}, {"setTiming", js_set_timing}, {"stats", js_stats},
       {"resetStats", js_reset_stats}, {"buildBVH", js_build_bvh}, {"buildBVHSAH", js_build_bvh_sah}, {"buildBVHDevice", js_build_bvh_device}, {"parseObj", js_parse_obj},
+      {"deviceCount", js_device_count}, {"reduceInfo", js_reduce_info},
   };
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
     napi_value f;
