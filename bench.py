@@ -78,7 +78,7 @@ def static_mix():
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r04_isa_histogram.json")))["kernels"]
         pick = {"k_shade": ("k_shade6<false, false>", "k_shade<true, true, false, false>"), "k_bvh": ("k_bvh2<false, true, false>",), "k_generate": ("k_generate<false>",),
-                "k_tail": ("k_tail<false, false, false, true>",), "k_accumulate": ("k_accumulate",)}
+                "k_tail": ("k_tail6<false, true>", "k_tail<false, false, false, true>"), "k_accumulate": ("k_accumulate",)}
         for k, names in pick.items():
             for name in names:
                 e = next((v for n, v in d.items() if name in n), None)
@@ -219,7 +219,7 @@ def pmc_passes(args, workload, log):
         for f in files:
             for row in csv.DictReader(open(f)):
                 k = row["Kernel_Name"].replace("ptmi::", "").replace("void ", "").split("(")[0].strip().split("<")[0]
-                k = {"k_bvh2": "k_bvh", "k_shade6": "k_shade"}.get(k, k)  # the traversal kernel's second edition and the 80-VGPR build of k_shade (round 3) are the same pipeline stages
+                k = {"k_bvh2": "k_bvh", "k_shade6": "k_shade", "k_tail6": "k_tail"}.get(k, k)  # the traversal kernel's second edition and the 80-VGPR build of k_shade (round 3) are the same pipeline stages
                 if k not in KERNELS:
                     continue
                 rec = out.setdefault(k, {})

@@ -139,12 +139,19 @@ def main():
     ap.add_argument("--pieces", action="store_true", help="instead: the building blocks of tools/isa_pieces.hip (norm3, div3, sqrt, rcp, rand, scatter, prims ...), one line each")
     ap.add_argument("--blocks", action="store_true", help="also list the largest basic blocks")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--product", action="store_true", help="the kernels bench.py's cost model reads (profiles/rNN_isa_histogram.json): tools/isa_histogram.py --product --json profiles/r04_isa_histogram.json")
     a = ap.parse_args()
     if a.pieces:
         return pieces(a)
     lines = assembly()
     ks = kernels(lines)
-    want = [s for s in ks if a.kernel.replace(" ", "") in demangle(s.lstrip(".L") if s.startswith(".L_Z") else s).replace(" ", "")]
+    dem = {s: demangle(s.lstrip(".L") if s.startswith(".L_Z") else s).replace(" ", "") for s in ks}
+    if a.product:
+        pats = ["k_shade6<true,false>(", "k_shade6<false,false>(", "k_shade<true,true,false,false>(", "k_bvh2<false,true,false>(", "k_bvh2<false,false,false>(", "k_accumulate(",
+                "k_tail<false,false,false,true>(", "k_tail6<false,true>(", "k_generate<false>("]
+        want = [s for s in ks if any(p in dem[s] for p in pats)]
+    else:
+        want = [s for s in ks if a.kernel.replace(" ", "") in dem[s]]
     if not want:
         sys.exit("no function matches; have: " + ", ".join(sorted(demangle(s) for s in ks))[:4000])
     w, src = issue_weights()

@@ -790,14 +790,14 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
 #endif
   ScopedSpan sp(c, T_BVH);
   // Stack entries per lane: the first tun.lds_stack (10) in LDS, the rest (rarely reached) in a per-wave spill area.
-  // 10 entries x 512 B + the candidate buffer = 5.5 KB per wave: 28 waves fit a CU's 160 KB, and the kernel's 66 VGPRs
+  // 10 entries x 512 B + the candidate buffer (1 KB since round 4's three-group scan) = 6 KB per wave: 26 waves fit a CU's 160 KB, and the kernel's 66 VGPRs
   // admit 7 waves per SIMD.  (Round 3: the kernel runs at the rate of the CU's L1 gather path — tools/gather_probe*.hip, 2.8 clocks per
   // 64-byte record — so occupancy beyond ~18 waves buys 0-3 %: configs[1] 4.53 -> 4.18 ms, configs[3] 482 -> 481.)
   const Tuning& tun = c->tun;
   const int sa = stack_alloc_for(c);
   const int le = std::min(sa, tun.lds_stack);
   const int se = sa - le;
-  const size_t lds = (size_t)le * 2 * 64 * sizeof(int) + 128 * sizeof(uint32_t);  // stacks (2 words/entry) + candidate buffer
+  const size_t lds = (size_t)le * 2 * 64 * sizeof(int) + kCandSlots * sizeof(uint32_t);  // stacks (2 words/entry) + candidate buffer
   // The abort of Q7 (hitRay.wgsl:106-109) needs sp to reach STACK_SIZE; sp never exceeds the number of inner nodes on a
   // root-to-leaf path.  PTMI_NOABORT=0 keeps the literal stack discipline for A/B runs.
   const bool noabort = c->bvh_depth < c->prm.stack_size && tun.noabort;
@@ -2091,6 +2091,18 @@ int ptmi_time_tally(ptmi_ctx* c, uint64_t* out, int n_regions, int reset) {
   if (reset) {
     static const unsigned long long zeros[2 * kTimeTallies] = {0};
     HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_time_tally), zeros, sizeof zeros));
+  }
+  return PTMI_OK;
+}
+// {wave-cycles, marks, lanes} per region of k_bvh since the last reset (BT() marks, ptmi_kernels.h; tools/bvh_regions.py)
+int ptmi_bvh_tally(ptmi_ctx* c, uint64_t* out, int n_regions, int reset) {
+  if (!c || !out || n_regions < 0 || n_regions > kBvhTallies) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_bvh_tally: bad argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bvh_tally), (size_t)n_regions * 24));
+  if (reset) {
+    static const unsigned long long zeros[3 * kBvhTallies] = {0};
+    HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_tally), zeros, sizeof zeros));
   }
   return PTMI_OK;
 }

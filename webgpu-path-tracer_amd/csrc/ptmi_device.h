@@ -223,6 +223,14 @@ DEV f3 refract3(f3 e1, f3 e2, float e3) {
 }
 
 // column-major mat4 (4 float4 columns) times (v, w): ((c0*x + c1*y) + c2*z) + c3*w
+DEV float4 mat_mul_cols(float4 c0, float4 c1, float4 c2, float4 c3, f3 v, float w) {
+  float4 r;
+  r.x = ((c0.x * v.x + c1.x * v.y) + c2.x * v.z) + c3.x * w;
+  r.y = ((c0.y * v.x + c1.y * v.y) + c2.y * v.z) + c3.y * w;
+  r.z = ((c0.z * v.x + c1.z * v.y) + c2.z * v.z) + c3.z * w;
+  r.w = ((c0.w * v.x + c1.w * v.y) + c2.w * v.z) + c3.w * w;
+  return r;
+}
 DEV float4 mat_mul(const float4* __restrict__ m, f3 v, float w) {
   float4 c0 = m[0], c1 = m[1], c2 = m[2], c3 = m[3];
   float4 r;
@@ -576,6 +584,16 @@ DEV void obj_ray_for(const DevScene& S, int mesh, int gid, f3 o, f3 d, ObjRay& r
   r.mesh = mesh;
 }
 
+// The same when every mesh of the scene shares one transform (S.uniform_gid >= 0: one mesh, or several placed together — every configuration of
+// BASELINE.json): the matrix comes through the scalar cache and the object-space ray is made ONCE, where the ray is picked up, so that a ray's first
+// triangle test no longer starts with a vector-memory round trip for the matrix (round 4: a fifth of k_bvh's wave-cycles went to the leaf phase).
+DEV void obj_ray_uniform(const DevScene& S, f3 o, f3 d, ObjRay& r) {
+  const float4* inv = S.xforms + 8 * S.uniform_gid + 4;
+  const float4 c0 = ldu(inv), c1 = ldu(inv + 1), c2 = ldu(inv + 2), c3 = ldu(inv + 3);
+  r.o = mk3(mat_mul_cols(c0, c1, c2, c3, o, 1.0f));
+  r.d = mk3(mat_mul_cols(c0, c1, c2, c3, d, 0.0f));
+}
+
 #ifdef PTMI_EXPERIMENTS  // the first edition of the traversal (rounds 1/2), kept for A/B builds only (_build.build_variant)
 // shaders/common.wgsl:191-222 (the accept/reject part; normal, p and material are reconstructed
 // from (index, u, v) by resolve_hit once the closest hit is final)
@@ -894,7 +912,7 @@ struct TriHit {
 template <bool COUNT>
 DEV void tri_test2(const DevScene& S, int k, float4 t0, float4 t1, float4 t2, float4 t3, f3 o, f3 d, ObjRay& orr, float& ct, TriHit& h, Counters& cn) {
   int mesh = __float_as_int(t0.w);
-  if (mesh != orr.mesh) obj_ray_for(S, mesh, __float_as_int(t2.w), o, d, orr);
+  if (S.uniform_gid < 0 && mesh != orr.mesh) obj_ray_for(S, mesh, __float_as_int(t2.w), o, d, orr);  // (uniform_gid >= 0: made at pick-up, obj_ray_uniform)
   if (COUNT) cn.tri_tests++;
   f3 A = mk3(t0), AB = mk3(t1), AC = mk3(t2), N = mk3(t3);
   float det = -dot3(orr.d, N);

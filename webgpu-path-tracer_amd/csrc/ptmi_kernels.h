@@ -279,30 +279,44 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
 //   * one shared pop section behind both kinds of step, on 8-byte LDS stack entries (ptmi_device.h).
 // (Storing an accepted hit at once instead of at the end of the ray saved four registers and lost 12 %: on gfx9 stores count on
 // vmcnt like loads, so every later fetch waited for them.)
+#ifdef PTMI_LANE_TALLY
+// k_bvh's stopwatch (measurement builds, tools/bvh_regions.py): a wave keeps cycles, marks and lanes per region in registers and adds them to
+// g_bvh_tally when it ends.  BT(k, dep, lanes) closes the interval since the previous mark and charges it to region k.
+enum : int { BT_SCAN = 0, BT_PICKUP = 1, BT_INNER_FETCH = 2, BT_INNER_STEP = 3, BT_LEAF_FETCH = 4, BT_LEAF_TEST = 5, BT_RETIRE = 6, BT_VOTE = 7, BT_CARRY = 8, BT_START = 9, kBvhTallies = 10 };
+__device__ unsigned long long g_bvh_tally[3 * kBvhTallies];  // {cycles, marks, lanes} per region
+#define BT(k, dep, lanes)                                                                                  \
+  do {                                                                                                     \
+    unsigned long long now_;                                                                               \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) : "v"(dep) : "memory");               \
+    bt_cyc[k] += now_ - bt_last, bt_marks[k] += 1u, bt_lanes[k] += (uint32_t)(lanes);                      \
+    bt_last = now_;                                                                                        \
+  } while (0)
+#else
+#define BT(k, dep, lanes) ((void)0)
+#endif
+constexpr int kScanGroups = 3, kCandSlots = 64 * (kScanGroups + 1);  // a pass adds at most 64 x kScanGroups candidates to fewer than 64
 template <bool COUNT, bool NOABORT, bool UNIFIED>
-__global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads, uint32_t n_teams, int stack_size,
-                                                           int lds_entries, int spill_entries, int2* __restrict__ spill, int refill_threshold, int leaf_batch,
-                                                           unsigned long long* __restrict__ totals, uint32_t range_cap, float4 cam,  // cam.w != 0: step 0's queue — every ray starts at cam.xyz
-                                                           Carry cy
+DEV void bvh2_body(const DevScene& S, const Paths& P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads, uint32_t n_teams, int stack_size, int lds_entries, int spill_entries,
+                   int2* __restrict__ spill, int refill_threshold, int leaf_batch, unsigned long long* __restrict__ totals, uint32_t range_cap, float4 cam, const Carry& cy,
+                   int* lds_stack, uint32_t wave_id, uint32_t n_waves  // (stand where blockIdx.x / gridDim.x would: a wave works on its own)
 #ifdef PTMI_EXPERIMENTS
-                                                           , const uint32_t* __restrict__ diag_order, const uint32_t* __restrict__ diag_keys
+                   , const uint32_t* __restrict__ diag_order, const uint32_t* __restrict__ diag_keys
 #endif
 ) {
 #ifndef PTMI_EXPERIMENTS
   static_assert(!UNIFIED, "the unified-fetch loop is an experiment (measured and dropped, DESIGN.md / profiles/NOTES_r03.md): build with -DPTMI_EXPERIMENTS");
 #endif
-  extern __shared__ int lds_stack[];
   const int lane = lane_id();
   LaneStack2 stk;
   stk.lds = (lds_v2i_t*)lds_stack + lane;
-  stk.spill = spill + (size_t)blockIdx.x * (size_t)spill_entries * 64 + lane;
+  stk.spill = spill + (size_t)wave_id * (size_t)spill_entries * 64 + lane;
   stk.lds_entries = lds_entries;
-  uint32_t* cand = reinterpret_cast<uint32_t*>(lds_stack + lds_entries * 2 * 64);  // [128] candidate slots
+  uint32_t* cand = reinterpret_cast<uint32_t*>(lds_stack + lds_entries * 2 * 64);  // [kCandSlots] candidate slots
   const uint32_t n_carried = cy.resv ? min(ctl->n_carried, cy.resv) : 0u;  // slots [0, n_carried) hold rays the previous launch carried over, [n_carried, resv) nothing
   uint32_t n = ctl->n_rays;
   if (n <= cy.resv && n_carried == 0u) n = 0u;  // nothing but the empty carry prefix
-  const uint32_t range = min(range_cap, max(64u, ((n / (2u * gridDim.x)) + 63u) & ~63u));
-  const uint32_t team = blockIdx.x % n_teams;
+  const uint32_t range = min(range_cap, max(64u, ((n / (2u * n_waves)) + 63u) & ~63u));
+  const uint32_t team = wave_id % n_teams;
   Counters cn = {0, 0, 0, 0, 0};
   uint32_t rb = 0, re = 0;   // this wave's claimed range of slots still to be scanned (wave-uniform)
   uint32_t ncand = 0;        // candidates waiting in `cand` (wave-uniform)
@@ -321,8 +335,14 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, 
   bool has = false;  // this lane holds a ray (traversing, or finished and not yet retired)
   const uint32_t root = __float_as_uint(S.root_lo.w);
   const uint32_t root_node = (root & REF_LEAF) ? root : (root & REF_IDX);
+#ifdef PTMI_LANE_TALLY
+  unsigned long long bt_cyc[kBvhTallies] = {0}, bt_last;
+  uint32_t bt_marks[kBvhTallies] = {0}, bt_lanes[kBvhTallies] = {0};
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bt_last)::"memory");
+#endif
   for (;;) {
     // retire finished rays (stores only): a triangle beat what part 1 had found; otherwise the record stands as it is
+    BT(BT_VOTE, 0.0f, 0);
     if (has && node == N_DONE) {
       if (hit.prim != 0u) {
         P.hin.tp[myslot] = make_float2(ct, __uint_as_float(hit.prim));
@@ -331,12 +351,15 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, 
       }
       has = false;
     }
+    BT(BT_RETIRE, 0.0f, 0);
     uint64_t hm = __ballot(node != N_DONE);
     int nact = __popcll(hm);
     if ((64 - nact) >= (nact == 0 ? 1 : refill_threshold)) {
       const uint32_t want = (uint32_t)(64 - nact);
       while (ncand < want && !(exhausted && rb == re)) {
         if (rb == re) {  // claim the next range of slots (see k_bvh)
+          // (Taking most ranges in a fixed order instead — wave w the ranges w, w + n_waves, ... — and claiming only the last quarter: configs[2] / [3]
+          // +40 % k_bvh time.  Waves that claim one after the other work on neighbouring stretches of the queue; that is worth more than the claims cost.)
           uint32_t i = 0;
           if (lane == 0) i = atomicAdd(&heads[team * kHeadStride], 1u);
           i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
@@ -349,19 +372,36 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, 
           rb = nb;
           re = min(nb + range, n);
         }
-        uint32_t slot = rb + (uint32_t)lane;
-        bool flagged;
 #ifdef PTMI_EXPERIMENTS
         if (diag_order) {  // PTMI_DIAG_SORT: the queue's BVH rays in an explicit, fully sorted order instead of slot order
-          flagged = slot < re && diag_keys[slot] != 0xffffffffu;
+          uint32_t slot = rb + (uint32_t)lane;
+          const bool flagged = slot < re && diag_keys[slot] != 0xffffffffu;
           if (flagged) slot = diag_order[slot];
-        } else
+          const uint64_t fm = __ballot(flagged);
+          if (flagged) cand[ncand + lanes_below(fm)] = slot;
+          ncand += (uint32_t)__popcll(fm);
+          rb = min(rb + 64u, re);
+          continue;
+        }
 #endif
-          flagged = slot < re && !dead_slot(slot, n_carried, cy.resv) && (P.hin.mat[slot] & HITMAT_BVH) != 0u;
-        const uint64_t fm = __ballot(flagged);
-        if (flagged) cand[ncand + lanes_below(fm)] = slot;
-        ncand += (uint32_t)__popcll(fm);
-        rb = min(rb + 64u, re);
+        // kScanGroups x 64 flag words per pass, the loads in flight together: where few slots are flagged (configs[1]: one in twelve — the mesh is
+        // small in the room) a refill is a chain of such round trips, and with the tree in LDS they were a quarter of the wave's time
+        uint32_t word[kScanGroups];
+#pragma unroll
+        for (int g = 0; g < kScanGroups; g++) {
+          const uint32_t slot = rb + 64u * (uint32_t)g + (uint32_t)lane;
+          word[g] = slot < re ? P.hin.mat[slot] : 0u;
+        }
+#pragma unroll
+        for (int g = 0; g < kScanGroups; g++) {
+          const uint32_t slot = rb + 64u * (uint32_t)g + (uint32_t)lane;
+          const bool flagged = (word[g] & HITMAT_BVH) != 0u && !dead_slot(slot, n_carried, cy.resv);
+          const uint64_t fm = __ballot(flagged);
+          if (flagged) cand[ncand + lanes_below(fm)] = slot;
+          ncand += (uint32_t)__popcll(fm);
+        }
+        rb = min(rb + 64u * (uint32_t)kScanGroups, re);
+        BT(BT_SCAN, 0.0f, ncand);
       }
       if (ncand) {
         const uint64_t idle = ~hm;
@@ -377,6 +417,7 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, 
           inv = rcp3_exact_il(d);
           negmask = (d.x < 0 ? 1u : 0u) | (d.y < 0 ? 2u : 0u) | (d.z < 0 ? 4u : 0u);
           orr.mesh = -1;
+          if (S.uniform_gid >= 0) obj_ray_uniform(S, o, d, orr);
           sp = 0;
           hit.prim = 0u;
           has = true;
@@ -393,6 +434,7 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, 
         ncand -= take;
         hm = __ballot(node != N_DONE);
         nact = __popcll(hm);
+        BT(BT_PICKUP, inv.x + ct, take);
       }
     }
     if (nact == 0) break;  // nothing in flight, nothing buffered, queue exhausted
@@ -443,23 +485,30 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, 
     // (configs[3]: 581 ms against 514 per 128 spp although it issues 11 % fewer vector and 46 % fewer memory instructions).
     do {
       const uint64_t pm = __ballot((int)node < 0), im = __ballot(node < N_INNER_LIMIT);
+      BT(BT_VOTE, 0.0f, 0);
       if (pm != 0ull && (__popcll(pm) >= leaf_batch || im == 0ull)) {
         if ((int)node < 0) {
           const int2 lc = (node & REF_MULTI) ? S.leaf_table[node & REF_IDX] : make_int2((int)(node & REF_IDX), 1);
           for (int j = 0; j < lc.y; j++) {  // one triangle per leaf with the reference's builder
             const float4* rec = S.pretri + 4 * (size_t)(lc.x + j);
             const float4 g0 = rec[0], g1 = rec[1], g2 = rec[2], g3 = rec[3];
+#ifdef PTMI_LANE_TALLY
+            if (j == 0) BT(BT_LEAF_FETCH, g0.x + g1.x + g2.x + g3.x, __popcll(__ballot(1)));
+#endif
             tri_test2<COUNT>(S, lc.x + j, g0, g1, g2, g3, o, d, orr, ct, hit, cn);
           }
           node = pop_until_pass2(stk, sp, ct, cn, COUNT);
         }
+        BT(BT_LEAF_TEST, ct, __popcll(pm));
       }
       if (node < N_INNER_LIMIT) {
         const float4* rec = S.pairs + 4 * (size_t)node;
         const float4 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3v = rec[3];
+        BT(BT_INNER_FETCH, f0.x + f1.x + f2.x + f3v.x, __popcll(__ballot(1)));
         node = inner_step2<COUNT, NOABORT>(f0, f1, f2, f3v, o, inv, S.tmin, negmask, ct, stack_size, stk, sp, cn);
         if (node == N_POP) node = pop_until_pass2(stk, sp, ct, cn, COUNT);
       }
+      BT(BT_INNER_STEP, __uint_as_float(node), __popcll(im));
       working = __popcll(__ballot(node != N_DONE));
       if (!more && may_carry && ++tail_iters >= cy.after) break;  // (wave-uniform)
     } while (working >= min_working);
@@ -496,9 +545,37 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, 
         }
       }
       if (__ballot(failed) != 0ull) may_carry = false;
+      BT(BT_CARRY, 0.0f, 0);
     }
   }
+#ifdef PTMI_LANE_TALLY
+  if (lane == 0)
+    for (int k = 0; k < kBvhTallies; k++) {
+      if (bt_marks[k] == 0u) continue;
+      atomicAdd(&g_bvh_tally[3 * k], bt_cyc[k]);
+      atomicAdd(&g_bvh_tally[3 * k + 1], (unsigned long long)bt_marks[k]);
+      atomicAdd(&g_bvh_tally[3 * k + 2], (unsigned long long)bt_lanes[k]);
+    }
+#endif
   if (COUNT) reduce_counters(cn, totals, true);
+}
+
+template <bool COUNT, bool NOABORT, bool UNIFIED>
+__global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads, uint32_t n_teams, int stack_size,
+                                                           int lds_entries, int spill_entries, int2* __restrict__ spill, int refill_threshold, int leaf_batch,
+                                                           unsigned long long* __restrict__ totals, uint32_t range_cap, float4 cam,  // cam.w != 0: step 0's queue — every ray starts at cam.xyz
+                                                           Carry cy
+#ifdef PTMI_EXPERIMENTS
+                                                           , const uint32_t* __restrict__ diag_order, const uint32_t* __restrict__ diag_keys
+#endif
+) {
+  extern __shared__ int lds_stack[];
+  bvh2_body<COUNT, NOABORT, UNIFIED>(S, P, ctl, heads, n_teams, stack_size, lds_entries, spill_entries, spill, refill_threshold, leaf_batch, totals, range_cap, cam, cy, lds_stack,
+                                     blockIdx.x, gridDim.x
+#ifdef PTMI_EXPERIMENTS
+                                            , diag_order, diag_keys
+#endif
+  );
 }
 
 #ifdef PTMI_EXPERIMENTS
@@ -1341,6 +1418,7 @@ DEV void tail_body(const DevScene& S, const RenderConst& rc, const Paths& P, Ste
         ObjRay orr;
         orr.mesh = -1;
         orr.o = orr.d = o;
+        if (S.uniform_gid >= 0) obj_ray_uniform(S, o, d, orr);
         TriHit hit = {0.0f, 0.0f, 0u, 0u};
         if (flagged && resume) {  // carried over by the last k_bvh launch: state word, stack and the closest hit so far come from the pool
           const uint32_t* rec = cy.pool_in + (size_t)st.slot * (size_t)cy.rec_words;
