@@ -1137,7 +1137,12 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
       const float4 a0 = r0[q], a1 = r1[q];
       TT(TT_RING_READ, a0.x + a1.x);
       rng = __float_as_uint(a0.w);
+#ifdef PTMI_PROBE_NO_FLUSH  // timing probe (wrong images): what does k_shade cost without hitScene part 1?
+      tp = make_float2(1.0f + a1.x * 0.0f, __uint_as_float((K_QUAD << 28) | 1u));
+      hm = 0u;
+#else
       prims_for_ray<COUNT>(S, mk3(a0), mk3(a1), rng, tp, hm, cn);
+#endif
       TT(TT_FLUSH_PRIMS, tp.x + __uint_as_float(hm));
       if (kMissShortcut && !MULTI && hm == HITMAT_MISS) {  // traceRay.wgsl:12-16 (see shade_body)
         LT(LT_MISS_SHORTCUT);
@@ -1212,8 +1217,8 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
     cnt -= take;
     TT(TT_FLUSH_STORE, 0.0f);
   };
-  // ray_color's loop body for the slots of the lanes with `active`; survivors go into the ring, a flush pass runs whenever 64 wait
-  auto shade_slots = [&](bool active, uint32_t slot) {
+  // ray_color's loop body for the slots of the lanes with `active`, their state in `st` (load_slot); survivors go into the ring
+  auto shade_group = [&](bool active, const SlotState& st) {
     bool survive = false, valid = false;
     NewState ns;  // (zeroed although only the survivors' values are read: left undefined, the allocator needs 8 registers more — scratch at 80 VGPRs)
     ns.o = ns.d = ns.T = mk3(0, 0, 0);
@@ -1221,7 +1226,6 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
     TT(TT_OTHER, 0.0f);  // (what came before this group: loop bookkeeping, the previous flush's tail)
     if (active) {
       LT(LT_GROUP);
-      const SlotState st = load_slot(P, slot, first != 0, rc);
       TT(TT_LOAD1, st.q0.x + st.q1.x + st.q2.x + st.tp.x + __uint_as_float(st.hitmat));  // the slot's state has arrived
       valid = __float_as_uint(st.q1.w) != PID_HOLE;
       if (valid) {
@@ -1242,16 +1246,45 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
     }
     cnt += (uint32_t)__popcll(mk);
     TT(TT_STAGE, 0.0f);
+  };
+  // ... a flush pass whenever 64 wait
+  auto shade_slots = [&](bool active, uint32_t slot) {
+    SlotState st;
+    if (active) st = load_slot(P, slot, first != 0, rc);
+    shade_group(active, st);
     if (cnt >= 64u) flush_pass(64u);
   };
   if (!SORT) {
-    for (uint32_t base = blockIdx.x * (uint32_t)kSChunk; base < n; base += gridDim.x * (uint32_t)kSChunk) {
-      const uint32_t m = min((uint32_t)kSChunk, n - base);
-#pragma unroll 1
-      for (uint32_t j0 = wv * 64u; j0 < m; j0 += kBlock) {
-        const uint32_t j = j0 + (uint32_t)lane;
-        shade_slots(j < m && !dead_slot(base + j, n_carried, resv), base + j);
+    // The wave's groups — slots base + j0 .. + 63 of the block's chunks — one after the other, the NEXT group's state requested before the flush pass of
+    // the current one: the loads travel while the wave tests quads (round 4: a wave spent 11 % of its cycles waiting for exactly these loads)
+    uint32_t base = blockIdx.x * (uint32_t)kSChunk, j0 = wv * 64u;
+    auto settle = [&]() {  // -> is there a group at (base, j0), moving on to the block's next chunk when this wave's groups of the current one are used up
+      while (base < n && j0 >= min((uint32_t)kSChunk, n - base)) {
+        base += gridDim.x * (uint32_t)kSChunk;
+        j0 = wv * 64u;
       }
+      return base < n;
+    };
+    auto fetch = [&](SlotState& st) {  // -> this lane's slot of group (base, j0) holds something; its state is on its way then
+      const uint32_t j = j0 + (uint32_t)lane;
+      const bool act = j < min((uint32_t)kSChunk, n - base) && !dead_slot(base + j, n_carried, resv);
+      if (act) st = load_slot(P, base + j, first != 0, rc);
+      return act;
+    };
+    SlotState cur;
+    bool have = settle(), cur_act = false;
+    if (have) cur_act = fetch(cur);
+#pragma unroll 1
+    while (have) {
+      shade_group(cur_act, cur);
+      j0 += kBlock;
+      have = settle();
+      SlotState nxt;
+      bool nxt_act = false;
+      if (have) nxt_act = fetch(nxt);
+      if (cnt >= 64u) flush_pass(64u);
+      cur = nxt;
+      cur_act = nxt_act;
     }
   } else {
     uint32_t* const bins = s_bin + wv * kBins * kRing;
@@ -1335,7 +1368,10 @@ __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, Re
   else shade_body_wave<IS, SORT, COUNT, MULTI>(S, rc, P, ctl, heads, totals, first, resv);
 }
 template <bool SORT, bool COUNT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_shade6(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl,
+#ifndef PTMI_SHADE6_WAVES
+#define PTMI_SHADE6_WAVES 6
+#endif
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PTMI_SHADE6_WAVES, 8))) void k_shade6(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl,
                                                                                                 uint32_t* __restrict__ heads, unsigned long long* __restrict__ totals, int first, uint32_t resv) {
   if constexpr (PTMI_SHADE_WAVE == 0 || (SORT && PTMI_SHADE_SORT_WAVE == 0)) shade_body<false, SORT, COUNT, false>(S, rc, P, ctl, heads, totals, first, resv);
   else shade_body_wave<false, SORT, COUNT, false>(S, rc, P, ctl, heads, totals, first, resv);
