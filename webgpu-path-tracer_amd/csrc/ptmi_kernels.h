@@ -1384,6 +1384,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PTMI_SHA
 // default MAX_BOUNCES = 100.  Launched in front of every step's k_bvh; declines (all blocks return at once) unless 0 < n_rays <= limit;
 // when it has run, the block that finishes last zeroes the queue length, so the step's k_bvh / k_shade and every later step find nothing.
 // Same per-ray arithmetic and visit order as the wavefront kernels (the same device functions), same counters and tallies.
+#ifndef PTMI_TAIL_TRAV_BATCH
+#define PTMI_TAIL_TRAV_BATCH 24
+#endif
+constexpr int kTailTravBatch = PTMI_TAIL_TRAV_BATCH;
 template <bool IS, bool COUNT, bool MULTI, bool NOABORT>
 DEV void tail_body(const DevScene& S, const RenderConst& rc, const Paths& P, StepCtl* __restrict__ ctl, unsigned long long* __restrict__ totals, int first, uint32_t limit,
                    int stack_size, int lds_entries, int spill_entries, int2* __restrict__ spill, const Carry& cy) {
@@ -1443,8 +1447,13 @@ DEV void tail_body(const DevScene& S, const RenderConst& rc, const Paths& P, Ste
     }
     {
       // ---- hitScene part 2 (hitRay.wgsl:42-110) for the lanes whose ray entered the root box ----
+      // ... once kTailTravBatch of them wait, or no other lane has anything to do: a lane whose ray needs the tree keeps it, untouched, while the others
+      // go on shading and bouncing.  (Round 4.  The wave walks the tree for as long as its longest ray; where one new ray in twelve enters the root box —
+      // configs[1] — that walk, five lanes wide, was most of what the kernel did.)
       const bool flagged = alive && (st.hitmat & HITMAT_BVH) != 0u;
-      if (__ballot(flagged) != 0ull) {
+      const uint64_t fmask = __ballot(flagged);
+      const bool more_to_take = !(pos == 64u && gnext * 64u >= n);  // (once the queue is used up there is nothing to gain by waiting: every pass the walk is put off lengthens the wave's end)
+      if (fmask != 0ull && ((int)__popcll(fmask) >= (more_to_take ? kTailTravBatch : 1) || __ballot(alive && !flagged) == 0ull)) {
         uint32_t node = flagged ? root_node : N_DONE;
         int sp = 0;
         const f3 o = mk3(st.q0), d = mk3(st.q1);
@@ -1488,20 +1497,22 @@ DEV void tail_body(const DevScene& S, const RenderConst& rc, const Paths& P, Ste
           uv = make_float2(hit.u, hit.v);
           st.hitmat = hit.mat;
         }
+        st.hitmat &= ~HITMAT_BVH;  // (the walk is done: the lane shades now)
       }
-      // ---- ray_color's loop body (traceRay.wgsl:10-80) ----
+      // ---- ray_color's loop body (traceRay.wgsl:10-80), for the lanes that do not wait for the tree ----
+      const bool go = alive && (st.hitmat & HITMAT_BVH) == 0u;
       NewState ns;  // (zeroed although only the survivors' values are read: left undefined, the allocator needs 8 registers more — scratch at 80 VGPRs)
       ns.o = ns.d = ns.T = mk3(0, 0, 0);
       ns.bounce = 0, ns.rng = 0, ns.pid = 0;
       bool survive = false;
-      if (alive) {
+      if (go) {
         tally++;
         const TriFetch tf = tri_fetch_uv(S, uv, __float_as_uint(st.tp.y));
         survive = shade_one<IS, MULTI>(S, rc, P, st, tf, L, ns);
+        alive = survive;
       }
-      alive = survive;
       // ---- hitScene part 1 for the new ray (hitRay.wgsl:6-54) ----
-      if (alive) {
+      if (go && alive) {
         uint32_t rng = ns.rng, hm;
         float2 tp;
         prims_for_ray<COUNT>(S, ns.o, ns.d, rng, tp, hm, cn);
