@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True, params=["wavefront", "mixed", "tail"])
 def pipeline(request, monkeypatch, ctx):
     """Every case three times: through the wavefront kernels alone (k_generate, k_bvh, k_shade per bounce), with the library's default
-    hand-over (k_tail traces a queue to the end once it is at most 2 Mi slots long at step 0, 512 Ki later: the small cases never leave
+    hand-over (k_tail traces a queue to the end once it is at most 2 Mi slots long at step 0, 1 Mi later: the small cases never leave
     k_tail, the full-size ones switch in mid-batch), and with k_tail taking every queue whole from step 0.  The library reads PTMI_TAIL_LIMIT
     when a context is created (contexts the tests make themselves) and in ptmi_reload_tuning (the session's context)."""
     if request.param == "wavefront":

@@ -823,7 +823,7 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
 #ifndef PTMI_MISS_SHORTCUT
 #define PTMI_MISS_SHORTCUT 1
 #endif
-constexpr int kTailLimitFirst = 2 << 20, kTailLimitLater = 512 << 10;  // k_tail takes a queue over when it is at most this long (slots): at step 0 (a lone 1080p frame fits) / later
+constexpr int kTailLimitFirst = 2 << 20, kTailLimitLater = 1 << 20;  // k_tail takes a queue over when it is at most this long (slots): at step 0 (a lone 1080p frame fits) / later (round 4: 512 Ki -> 1 Mi since its tree walk waits for 24 lanes — 8-frame batches of configs[1] +5 %, 64-frame ones and configs[2] unchanged: profiles/r04_tail_limit_ab.txt)
 constexpr int kTailRefill = 16;  // k_tail: idle lanes before a wave takes new paths
 constexpr bool kMissShortcut = PTMI_MISS_SHORTCUT != 0;  // A/B: settle definite misses in k_shade's flush phase
 constexpr int kSChunk = PTMI_SCHUNK;  // slots a k_shade block sorts, shades and compacts at a time
