@@ -2094,15 +2094,19 @@ int ptmi_time_tally(ptmi_ctx* c, uint64_t* out, int n_regions, int reset) {
   }
   return PTMI_OK;
 }
-// {wave-cycles, marks, lanes} per region of k_bvh since the last reset (BT() marks, ptmi_kernels.h; tools/bvh_regions.py)
-int ptmi_bvh_tally(ptmi_ctx* c, uint64_t* out, int n_regions, int reset) {
+// {wave-cycles, marks, lanes} per region of k_bvh (which = 0) or k_tail (which = 1) since the last reset (BT() marks, ptmi_kernels.h; tools/bvh_regions.py)
+int ptmi_bvh_tally(ptmi_ctx* c, uint64_t* out, int n_regions, int reset_and_which) {
   if (!c || !out || n_regions < 0 || n_regions > kBvhTallies) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_bvh_tally: bad argument");
+  const bool tail = (reset_and_which & 2) != 0, reset = (reset_and_which & 1) != 0;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  HIP_TRY(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bvh_tally), (size_t)n_regions * 24));
-  if (reset) {
-    static const unsigned long long zeros[3 * kBvhTallies] = {0};
-    HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_tally), zeros, sizeof zeros));
+  static const unsigned long long zeros[3 * kBvhTallies] = {0};
+  if (tail) {
+    HIP_TRY(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_tally), (size_t)n_regions * 24));
+    if (reset) HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_tail_tally), zeros, sizeof zeros));
+  } else {
+    HIP_TRY(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bvh_tally), (size_t)n_regions * 24));
+    if (reset) HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_tally), zeros, sizeof zeros));
   }
   return PTMI_OK;
 }

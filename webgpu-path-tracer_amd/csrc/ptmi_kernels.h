@@ -284,6 +284,8 @@ __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, S
 // g_bvh_tally when it ends.  BT(k, dep, lanes) closes the interval since the previous mark and charges it to region k.
 enum : int { BT_SCAN = 0, BT_PICKUP = 1, BT_INNER_FETCH = 2, BT_INNER_STEP = 3, BT_LEAF_FETCH = 4, BT_LEAF_TEST = 5, BT_RETIRE = 6, BT_VOTE = 7, BT_CARRY = 8, BT_START = 9, kBvhTallies = 10 };
 __device__ unsigned long long g_bvh_tally[3 * kBvhTallies];  // {cycles, marks, lanes} per region
+enum : int { TB_TAKE = 0, TB_WALK_FETCH = 1, TB_WALK_STEP = 2, TB_WALK_LEAF = 3, TB_SHADE = 4, TB_PRIMS = 5, TB_VOTE = 6 };  // k_tail's regions (same stopwatch)
+__device__ unsigned long long g_tail_tally[3 * kBvhTallies];
 #define BT(k, dep, lanes)                                                                                  \
   do {                                                                                                     \
     unsigned long long now_;                                                                               \
@@ -1416,8 +1418,14 @@ DEV void tail_body(const DevScene& S, const RenderConst& rc, const Paths& P, Ste
   bool resume = false;  // the lane's path was taken from the carry prefix: its hitScene part 2 goes on from the pool's record (first iteration only)
   float2 uv = make_float2(0.0f, 0.0f);  // barycentrics of the lane's triangle hit (the queue comes from k_generate / k_shade: none in it yet)
   uint32_t gnext = blockIdx.x, gbase = 0, pos = 64;  // next group to open; the open group's first slot and how many of its slots are taken
+#ifdef PTMI_LANE_TALLY
+  unsigned long long bt_cyc[kBvhTallies] = {0}, bt_last;
+  uint32_t bt_marks[kBvhTallies] = {0}, bt_lanes[kBvhTallies] = {0};
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bt_last)::"memory");
+#endif
 #pragma unroll 1
   for (;;) {
+    BT(TB_VOTE, 0.0f, 0);
     uint64_t am = __ballot(alive);
     const uint32_t nidle = 64u - (uint32_t)__popcll(am);
     if (nidle >= (uint32_t)kTailRefill || am == 0ull) {
@@ -1439,6 +1447,7 @@ DEV void tail_body(const DevScene& S, const RenderConst& rc, const Paths& P, Ste
         }
         pos += take;
         am = __ballot(alive);
+        BT(TB_TAKE, st.q1.x + st.tp.x + __uint_as_float(st.hitmat), take);
       }
     }
     if (am == 0ull) {
@@ -1484,13 +1493,16 @@ DEV void tail_body(const DevScene& S, const RenderConst& rc, const Paths& P, Ste
               tri_test2<COUNT>(S, lc.x + j, g0, g1, g2, g3, o, d, orr, ct, hit, cb);
             }
             node = pop_until_pass2(stk, sp, ct, cb, COUNT);
+            BT(TB_WALK_LEAF, ct, __popcll(__ballot(1)));
           }
           if (node < N_INNER_LIMIT) {
             const float4* rec = S.pairs + 4 * (size_t)node;
             const float4 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3v = rec[3];
+            BT(TB_WALK_FETCH, f0.x + f1.x + f2.x + f3v.x, __popcll(__ballot(1)));
             node = inner_step2<COUNT, NOABORT>(f0, f1, f2, f3v, o, inv, S.tmin, negmask, ct, stack_size, stk, sp, cb);
             if (node == N_POP) node = pop_until_pass2(stk, sp, ct, cb, COUNT);
           }
+          BT(TB_WALK_STEP, __uint_as_float(node), __popcll(__ballot(node != N_DONE)));
         }
         if (hit.prim != 0u) {  // a triangle beat what part 1 had found
           st.tp = make_float2(ct, __uint_as_float(hit.prim));
@@ -1511,6 +1523,7 @@ DEV void tail_body(const DevScene& S, const RenderConst& rc, const Paths& P, Ste
         survive = shade_one<IS, MULTI>(S, rc, P, st, tf, L, ns);
         alive = survive;
       }
+      BT(TB_SHADE, ns.o.x + ns.T.x, __popcll(__ballot(go)));
       // ---- hitScene part 1 for the new ray (hitRay.wgsl:6-54) ----
       if (go && alive) {
         uint32_t rng = ns.rng, hm;
@@ -1528,8 +1541,18 @@ DEV void tail_body(const DevScene& S, const RenderConst& rc, const Paths& P, Ste
           st.hitmat = hm;
         }
       }
+      BT(TB_PRIMS, st.tp.x, __popcll(__ballot(go && survive)));
     }
   }
+#ifdef PTMI_LANE_TALLY
+  if (lane == 0)
+    for (int k = 0; k < kBvhTallies; k++) {
+      if (bt_marks[k] == 0u) continue;
+      atomicAdd(&g_tail_tally[3 * k], bt_cyc[k]);
+      atomicAdd(&g_tail_tally[3 * k + 1], (unsigned long long)bt_marks[k]);
+      atomicAdd(&g_tail_tally[3 * k + 2], (unsigned long long)bt_lanes[k]);
+    }
+#endif
   for (int off2 = 32; off2 > 0; off2 >>= 1) tally += __shfl_down(tally, off2, 64);
   if (lane == 0 && tally) atomicAdd(tally_line(totals, blockIdx.x), tally);
   if (COUNT) {
