@@ -945,13 +945,15 @@ struct TriFetch {
   int gid;
 };
 DEV TriFetch tri_fetch(const DevScene& S, const float2* __restrict__ uvbuf, uint32_t slot, uint32_t prim) {
-  TriFetch f;  // (read by resolve_hit's K_TRI branch only: nothing to initialise for the other lanes — 14 moves per group)
+  TriFetch f;  // (read by resolve_hit's K_TRI and K_QUAD branches only: nothing to initialise for the other lanes — 14 moves per group)
+  const uint32_t idx = prim & 0x0fffffffu;
   if ((prim >> 28) == K_TRI) {
-    const uint32_t idx = prim & 0x0fffffffu;
     f.uv = uvbuf[slot];
     const float4* tn = S.trinorm + 3 * (size_t)idx;
     f.nA = tn[0], f.nB = tn[1], f.nC = tn[2];
     f.gid = __float_as_int(f.nA.w);  // = meshes[i32(nC.w)].global_id, put there by k_pretri_digest
+  } else if ((prim >> 28) == K_QUAD) {
+    f.nA = S.quad_unit_n[idx];  // a quad hit's unit normal rides in the same registers: asked for here, with everything else, instead of in the middle of resolve_hit (round 4)
   }
   return f;
 }
@@ -959,11 +961,13 @@ DEV TriFetch tri_fetch(const DevScene& S, const float2* __restrict__ uvbuf, uint
 DEV TriFetch tri_fetch_uv(const DevScene& S, float2 uv, uint32_t prim) {
   TriFetch f;
   f.uv = uv;
+  const uint32_t idx = prim & 0x0fffffffu;
   if ((prim >> 28) == K_TRI) {
-    const uint32_t idx = prim & 0x0fffffffu;
     const float4* tn = S.trinorm + 3 * (size_t)idx;
     f.nA = tn[0], f.nB = tn[1], f.nC = tn[2];
     f.gid = __float_as_int(f.nA.w);
+  } else if ((prim >> 28) == K_QUAD) {
+    f.nA = S.quad_unit_n[idx];
   }
   return f;
 }
@@ -984,7 +988,7 @@ DEV HitGeom resolve_hit(const DevScene& S, f3 o, f3 d, float t, const TriFetch& 
     g.front = true;
   } else if (kind == K_QUAD) {  // common.wgsl:176-183: normalize(quad.normal) is a per-quad constant, read from the digest
     LT(LT_RH_QUAD);
-    g.n = mk3(S.quad_unit_n[idx]);
+    g.n = mk3(tf.nA);  // = S.quad_unit_n[idx] (tri_fetch)
     g.front = dot3(d, g.n) < 0;
     if (!g.front) g.n = -g.n;
   } else {  // K_TRI, common.wgsl:224-237
