@@ -942,7 +942,8 @@ struct HitGeom {
 struct TriFetch {
   float2 uv;
   float4 nA, nB, nC;
-  int gid;
+  // (the mesh's transform index is nA.w — = meshes[i32(nC.w)].global_id, put there by k_pretri_digest — read where it is used: a copy made here would make
+  // the fetch wait for the record before the material's loads are even issued)
 };
 DEV TriFetch tri_fetch(const DevScene& S, const float2* __restrict__ uvbuf, uint32_t slot, uint32_t prim) {
   TriFetch f;  // (read by resolve_hit's K_TRI and K_QUAD branches only: nothing to initialise for the other lanes — 14 moves per group)
@@ -951,7 +952,6 @@ DEV TriFetch tri_fetch(const DevScene& S, const float2* __restrict__ uvbuf, uint
     f.uv = uvbuf[slot];
     const float4* tn = S.trinorm + 3 * (size_t)idx;
     f.nA = tn[0], f.nB = tn[1], f.nC = tn[2];
-    f.gid = __float_as_int(f.nA.w);  // = meshes[i32(nC.w)].global_id, put there by k_pretri_digest
   } else if ((prim >> 28) == K_QUAD) {
     f.nA = S.quad_unit_n[idx];  // a quad hit's unit normal rides in the same registers: asked for here, with everything else, instead of in the middle of resolve_hit (round 4)
   }
@@ -965,7 +965,6 @@ DEV TriFetch tri_fetch_uv(const DevScene& S, float2 uv, uint32_t prim) {
   if ((prim >> 28) == K_TRI) {
     const float4* tn = S.trinorm + 3 * (size_t)idx;
     f.nA = tn[0], f.nB = tn[1], f.nC = tn[2];
-    f.gid = __float_as_int(f.nA.w);
   } else if ((prim >> 28) == K_QUAD) {
     f.nA = S.quad_unit_n[idx];
   }
@@ -1000,7 +999,7 @@ DEV HitGeom resolve_hit(const DevScene& S, f3 o, f3 d, float t, const TriFetch& 
       const float4* m = S.xforms + 8 * S.uniform_gid + 4;
       c0 = ldu(m), c1 = ldu(m + 1), c2 = ldu(m + 2);
     } else {
-      const float4* m = S.xforms + 8 * tf.gid + 4;
+      const float4* m = S.xforms + 8 * __float_as_int(tf.nA.w) + 4;
       c0 = m[0], c1 = m[1], c2 = m[2];
     }
     g.n = norm3(mat_mul_transposed_dir(c0, c1, c2, nn));

@@ -696,8 +696,10 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
     LT(LT_HIT);
     int mat = (int)(st.hitmat & HITMAT_ID);
     Material m = load_material(S, mat);
-    // the chunk is sorted by this class, so `bin` is wave-uniform almost everywhere
-    const int bin = (m.type == 0.0f) ? BIN_LAMBERTIAN : (m.type == 1.0f) ? BIN_MIRROR : (m.type == 2.0f) ? BIN_GLASS : (m.type == 3.0f) ? BIN_ISOTROPIC : BIN_OTHER;
+    // The material's class: from the material word of the hit record (prepare_scene derives it from material_type exactly as scatterRay.wgsl's branches
+    // read it), not from the material's record — so that the scatter can start when the hit's normal has arrived and the record's albedo / emission are
+    // awaited where they are used, after it (round 4).  The chunk is sorted by this class, so `bin` is wave-uniform almost everywhere.
+    const int bin = (int)((st.hitmat >> HITMAT_BIN_SHIFT) & 7u);
     HitGeom g = resolve_hit(S, o, d, st.tp.x, tf, prim);
     TT(TT_LOAD2, g.n.x + m.type + m.color.x);  // the material's record and the hit's normal data have arrived
     f3 emission = m.emission;
