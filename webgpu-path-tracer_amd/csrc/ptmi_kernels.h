@@ -392,12 +392,12 @@ DEV void bvh2_body(const DevScene& S, const Paths& P, StepCtl* __restrict__ ctl,
 #pragma unroll
         for (int g = 0; g < kScanGroups; g++) {
           const uint32_t slot = rb + 64u * (uint32_t)g + (uint32_t)lane;
-          word[g] = slot < re ? P.hin.mat[slot] : 0u;
+          word[g] = P.hin.mat[min(slot, re - 1u)];  // (no branch around the load: under one, each of the three got an s_waitcnt of its own and they went one after the other; rb < re here)
         }
 #pragma unroll
         for (int g = 0; g < kScanGroups; g++) {
           const uint32_t slot = rb + 64u * (uint32_t)g + (uint32_t)lane;
-          const bool flagged = (word[g] & HITMAT_BVH) != 0u && !dead_slot(slot, n_carried, cy.resv);
+          const bool flagged = slot < re && (word[g] & HITMAT_BVH) != 0u && !dead_slot(slot, n_carried, cy.resv);
           const uint64_t fm = __ballot(flagged);
           if (flagged) cand[ncand + lanes_below(fm)] = slot;
           ncand += (uint32_t)__popcll(fm);
