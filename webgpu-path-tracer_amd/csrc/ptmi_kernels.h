@@ -895,12 +895,15 @@ DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, St
     if (SORT) {
       // ---- 1: sort ----
       uint32_t keys[kSChunk / kBlock];
+      uint32_t words[kSChunk / kBlock];  // the thread's material words, asked for together (with a branch around each load they went one after the other: round 4's reading of the ISA)
+#pragma unroll
+      for (int r = 0; r < kSChunk / kBlock; r++) words[r] = P.hin.mat[base + min((uint32_t)r * kBlock + threadIdx.x, m - 1u)];
 #pragma unroll
       for (int r = 0; r < kSChunk / kBlock; r++) {
         const uint32_t j = (uint32_t)r * kBlock + threadIdx.x;
         int bin = -1;
         if (j < m && !dead_slot(base + j, n_carried, resv)) {
-          const uint32_t b = (P.hin.mat[base + j] >> HITMAT_BIN_SHIFT) & 7u;
+          const uint32_t b = (words[r] >> HITMAT_BIN_SHIFT) & 7u;
           if (b < (uint32_t)NUM_BINS) bin = (int)b;  // 7 = hole
         }
         uint32_t rank = 0;
