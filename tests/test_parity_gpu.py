@@ -501,6 +501,38 @@ def test_random_scenes_bit_exact(ctx, pkg, oracle, seed):
         assert st[k] == ost[k], (seed, k, st[k], ost[k])
 
 
+@pytest.mark.parametrize("seed", [2, 5, 11])
+def test_unknown_material_types_bit_exact(ctx, pkg, oracle, seed):
+    """material_type values scatterRay.wgsl has no branch for (4, 7.5, -1, NaN): material_scatter falls through and the ray goes on from what the
+    private scatter record holds (Q13).  The kernels take a material's class from the hit record's material word (prepare_scene), not from the
+    record itself: this is the case where the two could part."""
+    sc, r = _random_scene(pkg, seed)
+    b = dict(sc.buffers(native=pkg.ptmi.NativeHost()))
+    mats = np.array(b["materials"], np.float32).reshape(-1, 16)
+    odd = [4.0, 7.5, -1.0, float("nan")]
+    for i in range(0, mats.shape[0], 2):
+        mats[i, 14] = odd[(i // 2) % len(odd)]
+    b["materials"] = mats.reshape(-1)
+    params = dict(max_bounces=6, stack_size=20, importance_sampling=0)
+    ctx.upload_scene(b)
+    ctx.resize(48, 36)
+    view = cornell_view(pkg, "cornell")
+    ctx.set_params(**dict(params, importance_sampling=1))  # (with importance sampling the shader would read a stale scatter record: refused)
+    with pytest.raises(pkg.PtmiError):
+        ctx.render(view, 3, 1)
+    ctx.set_params(**params)
+    ctx.reset_stats()
+    ctx.set_counters(True)
+    ctx.render(view, 3, 3)
+    got = ctx.read_framebuffer()
+    st = ctx.stats()
+    ctx.set_counters(False)
+    want, ost = oracle.render(b, 48, 36, view, 3, 3, **params)
+    assert_same_bits(got, want, "unknown material types, scene %d" % seed)
+    for k in ("rays", "paths", "node_visits", "tri_tests", "sphere_tests", "quad_tests", "mat_fetches"):
+        assert st[k] == ost[k], (seed, k, st[k], ost[k])
+
+
 def test_device_bvh_builder_is_byte_identical_to_host(ctx, pkg):
     """ptmi_build_bvh_device (level-synchronous, rocPRIM segmented reduce + stable segmented radix sort) against the host builder
     — itself byte-identical to the reference's JavaScript (tests/test_host_buffers.py): random boxes with tied keys and -0, tiny
