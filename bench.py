@@ -344,7 +344,7 @@ def roofline_of(tab, dom, timed_ms_per_launch, timed_launches, gather_records_pe
 # ---------------------------------------------------------------------------------------------------- one GPU measurement
 class _NoDist:
     """Stand-in for webgpu_path_tracer_amd.dist when there is one process (no torch import at all: a fresh box pays 1-2 minutes for it)."""
-    TILE_PIXELS = 4096
+    TILE_PIXELS = 4032
 
     @staticmethod
     def barrier():

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One rank of an N-GPU run, timed on ONE GPU: what each rank of bench.py --gpus N would do, without the other ranks.
 
-Every rank of an N-GPU render traces the pixel tiles t with t % N == rank (4096-pixel tiles, ptmi_set_shard) — here rank 0 of N for N = 1, 2, 4, 8 —
+Every rank of an N-GPU render traces the pixel tiles t with t % N == rank (4032-pixel tiles, ptmi_set_shard) — here rank 0 of N for N = 1, 2, 4, 8 —
 in both scaling modes of bench.py: `weak` (spp x N: every rank keeps the rays of the 1-GPU run) and `strong` (fixed total spp: every rank traces 1/N of the
 rays).  The step's collective cannot run on one GPU; its size is stated instead (bytes landing on the root per step, for the full-buffer reduce and for
 the gather of owned tiles), with the time they need at a stated per-link xGMI rate, so that the projected N-GPU figure = N x rays / (rank time + collective).
@@ -27,7 +27,7 @@ def main():
     pkg = entry._load_pkg()
     workloads = sys.argv[1:] or ["c2", "c3"]
     out = {"note": __doc__.strip().splitlines()[0], "xgmi_link_gbs_assumed": XGMI_LINK_GBS, "rccl_reduce_busbw_gbs_assumed": RCCL_REDUCE_BUSBW_GBS,
-           "collective_latency_ms_assumed": COLLECTIVE_LATENCY_MS, "tile_pixels": 4096, "workloads": {}}
+           "collective_latency_ms_assumed": COLLECTIVE_LATENCY_MS, "tile_pixels": 4032, "workloads": {}}
     for w in workloads:
         class A:
             width, height, bounces, bvh, tris, stack_size, frames_in_flight = 1920, 1080, 8, "median", 0, 0, 0
@@ -37,7 +37,7 @@ def main():
         fb_bytes = A.width * A.height * 16
         rows = []
         for world in (1, 2, 4, 8):
-            ctx.set_shard(0, world, 4096)
+            ctx.set_shard(0, world, 4032)
             for mode in ("weak", "strong"):
                 if world == 1 and mode == "strong":
                     continue

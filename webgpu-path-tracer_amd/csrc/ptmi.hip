@@ -212,7 +212,7 @@ struct ptmi_ctx {
   bool shares_device = false;  // another shard of the same multi-device context lives on this GPU
   std::vector<ptmi_ctx*> peers;
   PeerWorker* worker = nullptr;  // a peer's host thread (created on first use)
-  int proc_rank = 0, proc_world = 1, proc_tile = 4096;
+  int proc_rank = 0, proc_world = 1, proc_tile = 4032;  // (63 waves of pixels; not 4096: see dist.py — a rank's pixel count must not be a large power of two)
   bool use_rccl = false;
   std::vector<ncclComm_t> comms;  // one per local device, same order as {this, peers...}
   int reduce_mode = 0;            // ptmi_stats.reduce_mode: how the multi-device sum runs (0 single device, 1 RCCL, 2 peer copies + add, 3 the same as a FALLBACK)

@@ -10,9 +10,12 @@ adds x + 0 + ... + 0, so the N-GPU image is bit-identical to the 1-GPU image.
 """
 import os
 
-TILE_PIXELS = 4096  # contiguous pixel runs per shard tile (about two 1080p rows): long enough for coherent
-                    # primary-ray waves, short enough (506 tiles at 1080p) that every rank samples every
-                    # image region and the per-rank work is balanced
+TILE_PIXELS = 4032  # contiguous pixel runs per shard tile (about two 1080p rows, 63 waves): long enough for coherent
+                    # primary-ray waves, short enough (515 tiles at 1080p) that every rank samples every
+                    # image region and the per-rank work is balanced.  NOT 4096: a rank's pixel count is the
+                    # stride between the frames of a batch in every per-path array, and 64 tiles x 4096 = 2^18
+                    # pixels (rank 0 of 8 at 1080p) puts the same pixel of the frames in flight into the same HBM
+                    # channels: k_shade +12 %, one rank of eight 7 % slower (profiles/r04_shard_tile.txt)
 
 
 def env_rank_world():
