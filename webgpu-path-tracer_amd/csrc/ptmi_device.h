@@ -393,12 +393,16 @@ DEV uint32_t local_to_pixel(const RenderConst& rc, uint32_t j) {
 DEV f3 cam_origin(const RenderConst& rc) { return mk3(rc.cam_o[0], rc.cam_o[1], rc.cam_o[2]); }
 
 // shaders/main.wgsl:3-8 + shaders/shootRay.wgsl:5-60: jittered camera ray for sample k of a pixel
-DEV void camera_ray(const RenderConst& rc, uint32_t pix, int k, uint32_t& rng, f3& o, f3& d) {
-  const float W = rc.W, H = rc.H;
+// ... in two parts: what depends on the pixel alone (k_generate makes it once per pixel for all the frames of a batch), and the rest
+DEV void camera_pixel(const RenderConst& rc, uint32_t pix, float& px, float& py) {
+  const float W = rc.W;
   float fidx = (float)pix;
   float q = fidx / W;
-  float px = fidx - W * truncf(q);  // f32 %: x - y*trunc(x/y)
-  float py = q;                     // not floored (Q1)
+  px = fidx - W * truncf(q);  // f32 %: x - y*trunc(x/y)
+  py = q;                     // not floored (Q1)
+}
+DEV void camera_ray_at(const RenderConst& rc, float px, float py, int k, uint32_t& rng, f3& o, f3& d) {
+  const float W = rc.W, H = rc.H;
   float a, b;
   if (rc.stratify) {
     float i = (float)(k / rc.strat_side), j = (float)(k % rc.strat_side);
@@ -417,6 +421,11 @@ DEV void camera_ray(const RenderConst& rc, uint32_t pix, int k, uint32_t& rng, f
   float len = sqrt_exact(((dx * dx + dy * dy) + dz * dz) + dw * dw);  // normalize() of the vec4, then .xyz
   d = mk3(dx, dy, dz) / len;
   o = cam_origin(rc);
+}
+DEV void camera_ray(const RenderConst& rc, uint32_t pix, int k, uint32_t& rng, f3& o, f3& d) {
+  float px, py;
+  camera_pixel(rc, pix, px, py);
+  camera_ray_at(rc, px, py, k, rng, o, d);
 }
 
 // Loads whose address is the same for every lane of a wave (primitive tables walked by a wave-uniform loop index):
