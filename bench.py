@@ -123,20 +123,26 @@ def make_workload(pkg, name, args):
             raise SystemExit("--bvh sah needs a workload built through the Scene API (c3, c4, c5)")
         wl["buffers"] = pkg.scenes.golden_buffers("c2")  # reference-generated buffers of configs[1] (tests/golden)
         wl["label"], wl["stack"] = "configs[1]: Cornell + monkey_968.obj (967 tris)", args.stack_size or 20
-    elif name == "c3":
-        wl["buffers"] = pkg.scenes.c3_scene(**tri_kw).buffers(native=native, sah=sah)  # procedural stand-in, 871,414 tris
-        wl["label"], wl["stack"] = "configs[2]: Cornell + dragon-class mesh (871,414 tris, procedural stand-in for stanfordDragon.obj)", args.stack_size or 24
-    elif name == "c4":
-        wl["buffers"] = pkg.scenes.c4_scene(**tri_kw).buffers(native=native, sah=sah)
-        wl["label"], wl["stack"], wl["cam"] = "configs[3]: sponza-class interior (262,267 tris, procedural stand-in for sponzaAtrium.obj), camera inside", args.stack_size or 24, "interior"
     else:
-        wl["buffers"] = pkg.scenes.c5_scene(**tri_kw).buffers(native=native, sah=sah)
-        wl["label"], wl["stack"], wl["extra"] = "configs[4]: Cornell + buddha-class glass mesh (1,087,716 tris, procedural stand-in for buddha.obj), importance sampling", args.stack_size or 24, dict(importance_sampling=1)
-        if wl["bounces"] == 8:
-            wl["bounces"] = 16
+        # --bvh sah: the scene goes up unbuilt and the tree is made where the triangles are (ptmi_build_scene_bvh_sah, make_context); its depth is
+        # known only then, and the SAH trees of these meshes are 27-31 deep: STACK_SIZE has to exceed that or the reference's stack-full abort (Q7) cuts rays
+        def buffers(sc):
+            return sc.buffers_unbuilt() if sah else sc.buffers(native=native)
+        wl["device_sah"] = sah
+        if name == "c3":
+            wl["buffers"] = buffers(pkg.scenes.c3_scene(**tri_kw))  # procedural stand-in, 871,414 tris
+            wl["label"], wl["stack"] = "configs[2]: Cornell + dragon-class mesh (871,414 tris, procedural stand-in for stanfordDragon.obj)", args.stack_size or (40 if sah else 24)
+        elif name == "c4":
+            wl["buffers"] = buffers(pkg.scenes.c4_scene(**tri_kw))
+            wl["label"], wl["stack"], wl["cam"] = "configs[3]: sponza-class interior (262,267 tris, procedural stand-in for sponzaAtrium.obj), camera inside", args.stack_size or (40 if sah else 24), "interior"
+        else:
+            wl["buffers"] = buffers(pkg.scenes.c5_scene(**tri_kw))
+            wl["label"], wl["stack"], wl["extra"] = "configs[4]: Cornell + buddha-class glass mesh (1,087,716 tris, procedural stand-in for buddha.obj), importance sampling", args.stack_size or (40 if sah else 24), dict(importance_sampling=1)
+            if wl["bounces"] == 8:
+                wl["bounces"] = 16
     wl["view"] = pkg.scenes.camera_view(*pkg.scenes.CAMERAS[wl["cam"]])
     wl["native"] = native
-    if name != "c2":
+    if name != "c2" and not sah:
         wl["setup"]["host_scene_and_packing_ms"] = (time.perf_counter() - t0) * 1e3 - native.bvh_ms  # Python mirror of lib/scene.js (+ the procedural mesh): not the product
         wl["setup"]["bvh_build_native_host_ms"] = native.bvh_ms
     return wl
@@ -146,10 +152,24 @@ def make_context(pkg, wl, device, args):
     ctx = pkg.Context(device)
     t = time.perf_counter()
     ctx.upload_scene(wl["buffers"])
+    ms = (time.perf_counter() - t) * 1e3
+    if wl.get("device_sah") and not wl.get("bvh_host"):
+        t = time.perf_counter()
+        ctx.build_scene_bvh(sah=True)
+        wl["setup"]["build_scene_bvh_sah_device_ms"] = (time.perf_counter() - t) * 1e3  # boxes + binned-SAH build + triangles into leaf order, all on the GPU
+        info = ctx.scene_bvh_info()
+        wl["setup"]["sah_tree"] = {"nodes": info["nodes"], "depth": info["depth"]}
+        if info["depth"] >= wl["stack"]:
+            raise SystemExit("--stack-size %d does not exceed the SAH tree's depth %d" % (wl["stack"], info["depth"]))
+        # the oracle (cpu_baseline), the compulsory-bytes figure and any further context of this run want the tree and the reordered triangles on the host
+        n_tri = np.asarray(wl["buffers"]["triangles"]).size // 24
+        wl["buffers"] = dict(wl["buffers"], bvh=ctx.read_scene_buffer("bvh", info["nodes"]).reshape(-1), triangles=ctx.read_scene_buffer("triangles", n_tri).reshape(-1))
+        wl["bvh_host"] = True
+    t = time.perf_counter()
     ctx.set_params(max_bounces=wl["bounces"], frames_in_flight=args.frames_in_flight, stack_size=wl["stack"], **wl["extra"])
     ctx.resize(wl["W"], wl["H"])
     ctx.prepare()  # validation + digests + upload, synchronous
-    wl["setup"]["upload_validate_digests_ms"] = (time.perf_counter() - t) * 1e3
+    wl["setup"]["upload_validate_digests_ms"] = ms + (time.perf_counter() - t) * 1e3
     return ctx
 
 

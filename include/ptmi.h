@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PTMI_API_VERSION 4
+#define PTMI_API_VERSION 5
 
 typedef struct ptmi_ctx ptmi_ctx;
 
@@ -232,8 +232,18 @@ int ptmi_selftest(ptmi_ctx* ctx, int which, uint64_t* mismatches, uint32_t* firs
  * until it is built again (or a BVH is uploaded).  At most 2^23 triangles: node ids are f32 in the rows (exact below 2^24), as in the
  * reference's own format — more returns PTMI_ERR_UNSUPPORTED. */
 int ptmi_build_scene_bvh(ptmi_ctx* ctx);
+/* API v5.  The same with the reference's OTHER builder, BVH.generate_bvh_heirarchy_SAH (lib/BVH/bvhNode.js:108-283: 8 bins per axis, leaf when the best plane
+ * costs no less than the node), which the reference ships but never calls (lib/BVH/bvhBuilder.js:10-13 takes the median split): an opt-in for callers
+ * who want the cheaper traversal (benchmarks.txt:2-12) and accept a tree the reference's renderer does not use.  Level-synchronous on the GPU
+ * (csrc/ptmi_bvh_device.hip), rows byte-identical to ptmi_build_bvh_sah's; leaves may hold several triangles, so the row count is not 2n - 1:
+ * ptmi_scene_bvh_info reports it.  The image is the one the reference's shader renders from that tree (same traversal code), not the median tree's
+ * bit for bit: triangle test order and the stack-depth abort (Q7) depend on the tree — use stack_size > depth. */
+int ptmi_build_scene_bvh_sah(ptmi_ctx* ctx);
+/* Rows (nodes) and depth (inner nodes on the longest root-to-leaf path; valid after ptmi_prepare for an uploaded tree) of the scene's BVH, and whether it
+ * lives on the device only (ptmi_build_scene_bvh*).  Any pointer may be NULL. */
+int ptmi_scene_bvh_info(ptmi_ctx* ctx, uint64_t* n_nodes, int32_t* depth, int32_t* on_device);
 /* Test / tool hook: copies the context's triangles (which = 5: in their current order) or BVH rows (which = 9) to the host; bytes must be
- * exactly the buffer's size (triangles x 96, (2 x triangles - 1) x 48 for a tree from ptmi_build_scene_bvh). */
+ * exactly the buffer's size (triangles x 96, ptmi_scene_bvh_info's n_nodes x 48 for a device-resident tree). */
 int ptmi_read_scene_buffer(ptmi_ctx* ctx, int which, void* dst, size_t bytes);
 
 /* ---- host-side natives (no GPU needed) -------------------------------------------------------- */
@@ -258,6 +268,11 @@ int ptmi_build_bvh_sah(size_t n_prims, const double* bmin, const double* bmax, i
  * (the host builder: 0.13-0.17 s on a 32-thread share of the GPU box, 1.75 s on 8 cores).  Synchronous. */
 int ptmi_build_bvh_device(ptmi_ctx* ctx, size_t n_prims, const double* bmin, const double* bmax, int prim_type, float* nodes_out,
                           int64_t* order_out);
+/* API v5.  ptmi_build_bvh_sah on the GPU of `ctx` (csrc/ptmi_bvh_device.hip: per level one reduce-by-key for boxes and centroid bounds, LDS-privatised
+ * binning, one thread per node for the 21 candidate planes, the median builder's two stable radix sorts, an atomicMin for the split position; pre-order
+ * ids from subtree sizes).  Same arguments, byte-identical output.  Synchronous. */
+int ptmi_build_bvh_sah_device(ptmi_ctx* ctx, size_t n_prims, const double* bmin, const double* bmax, int prim_type, float* nodes_out,
+                              int64_t* order_out, size_t* n_nodes_out);
 
 /* OBJ text -> de-indexed vertex / normal arrays with the reference's accepted grammar and quirks
  * (lib/primitives/objReader.js:10-68: `v`, `vn`, `f a/b/c` triangles; tokens go through JS Number()).  The arrays are

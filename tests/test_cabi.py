@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert sorted(pkg.ptmi.SYMBOLS) == declared
     for name in declared:
         assert hasattr(L, name), name
-    assert L.ptmi_version() == 4
+    assert L.ptmi_version() == 5
 
 
 def test_status_strings_and_defaults(pkg):

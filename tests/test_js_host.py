@@ -33,7 +33,7 @@ def test_addon_loads_and_exports_surface(pkg):
     assert os.path.exists(os.path.join(JS, "ptmi.node")), "run __graft_entry__.build()"
     out = _run([node, "-e", "const p=require('./ptmi.node');console.log(JSON.stringify({v:p.version(),k:Object.keys(p).sort(),buf:p.BUF,d:p.defaultParams()}))"], cwd=JS)
     o = json.loads(out)
-    assert o["v"] == 4
+    assert o["v"] == 5
     assert set(o["k"]) >= {"create", "prepare", "destroy", "upload", "resize", "renderFrame", "render", "readFramebuffer", "stats", "buildBVH", "buildBVHSAH", "buildBVHDevice", "parseObj", "setParams", "resolveRGBA8", "deviceCount", "reduceInfo"}
     assert o["buf"] == pkg.ptmi.BUF
     assert o["d"]["max_bounces"] == 100 and o["d"]["stack_size"] == 20 and o["d"]["background"] == [0, 1, 1]

@@ -303,8 +303,8 @@ def test_dragon_class_scene_bit_exact(ctx, pkg, oracle):
         assert_same_bits(got, want, "c3 stack %d" % stack)
         for k in ("rays", "node_visits", "tri_tests", "quad_tests", "mat_fetches"):
             assert st[k] == ost[k], (stack, k)
-    # the same 40 k-triangle SAH interior at a full 1920x1080 frame (the image size of configs[2] / [3], not their scenes), stack_size 24
-    _full_size_windows(ctx, oracle, b, view, 1920, 1080, 3, dict(max_bounces=8, stack_size=24), "40 k-triangle SAH interior at 1080p")
+    # configs[2] itself at its full image size: the 871,414-triangle scene, 1920x1080, stack_size 24, three oracle windows of 6000 pixels
+    _full_size_windows(ctx, oracle, b, view, 1920, 1080, 3, dict(max_bounces=8, stack_size=24), "configs[2] (871,414 triangles) at 1080p")
 
 
 @pytest.mark.parametrize("name,cam,params", [
@@ -557,6 +557,77 @@ def test_device_bvh_builder_is_byte_identical_to_host(ctx, pkg):
     a, oa = nh.build_bvh(bmin, bmax)
     b, ob = ctx.build_bvh(bmin, bmax)
     assert np.array_equal(oa, ob) and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_device_sah_builder_is_byte_identical_to_host(ctx, pkg):
+    """ptmi_build_bvh_sah_device (level-synchronous binned SAH: reduce-by-key, LDS-privatised bins, one thread per node for the 21 planes, stable
+    radix sorts, atomicMin split) against ptmi_build_bvh_sah on the host — itself pinned to the reference's JavaScript (tests/golden/c2sah_bvh.bin,
+    tests/test_host_buffers.py): random boxes with tied keys and -0, coincident boxes (leaves of several primitives), tiny inputs, flat
+    distributions, and the meshes of configs[3] and configs[2]."""
+    nh = pkg.ptmi.NativeHost()
+    rng = np.random.default_rng(23)
+    for n in (1, 2, 3, 5, 64, 1000, 70001):
+        c = rng.uniform(-1, 1, (n, 3)).astype(np.float32).astype(np.float64)
+        c[rng.integers(0, n, n // 3)] = c[0]        # coincident boxes: no plane separates them -> leaves of several primitives; tied keys: stability decides
+        c[rng.integers(0, n, max(n // 10, 1)), 1] = -0.0
+        c[rng.integers(0, n, max(n // 10, 1)), 1] = 0.0
+        if n == 1000:
+            c[:, 2] = 0.25                          # a flat cloud: one axis has no extent (bounds_min == bounds_max)
+        e = rng.uniform(0, 0.05, (n, 3))
+        a, oa = nh.build_bvh_sah(c - e, c + e)
+        b, ob = ctx.build_bvh_sah(c - e, c + e)
+        assert a.shape == b.shape, (n, a.shape, b.shape)
+        assert np.array_equal(oa, ob), n
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), n
+        if n >= 64:
+            assert (a[a[:, 7] == 2][:, 9] > 1).any(), n  # the case it is here for
+    for make in (pkg.scenes.c4_scene, pkg.scenes.c3_scene):
+        sc = make()
+        sc.init_mesh_data()
+        sc.create_meshes()
+        bmin = np.concatenate([m.bmin for m in sc.meshes])
+        bmax = np.concatenate([m.bmax for m in sc.meshes])
+        a, oa = nh.build_bvh_sah(bmin, bmax)
+        b, ob = ctx.build_bvh_sah(bmin, bmax)
+        assert a.shape == b.shape and np.array_equal(oa, ob) and np.array_equal(a.view(np.uint32), b.view(np.uint32)), make.__name__
+
+
+def test_scene_sah_bvh_built_on_the_device_is_the_host_pipeline_bit_for_bit(ctx, pkg, oracle):
+    """ptmi_build_scene_bvh_sah: the whole of Scene.create_bvh(sah=True) on the GPU — boxes, the binned-SAH build, the triangles into leaf order, pair
+    records AND the leaf table of the leaves that hold several triangles — against the host pipeline: same rows, same triangle order, same image and
+    counters (stack_size above the tree's depth, and 20: the literal stack discipline with the Q7 abort live); then configs[3]'s own scene
+    (262,267 triangles) from its device-built SAH tree at 1920x1080 on oracle windows."""
+    for name, make, view in (("40 k-triangle interior", lambda: pkg.scenes.c4_scene(40000), cornell_view(pkg, "interior")), ("two transformed meshes", lambda: _two_mesh_scene(pkg), cornell_view(pkg))):
+        host = make().buffers(native=pkg.ptmi.NativeHost(), sah=True)
+        raw = make().buffers_unbuilt()
+        n_tri = raw["triangles"].size // 24
+        ctx.upload_scene(raw)
+        ctx.build_scene_bvh(sah=True)
+        info = ctx.scene_bvh_info()
+        assert info["on_device"] and info["nodes"] == host["bvh"].size // 12, (name, info)
+        rows = ctx.read_scene_buffer("bvh", info["nodes"])
+        tris = ctx.read_scene_buffer("triangles", n_tri)
+        assert np.array_equal(rows.reshape(-1).view(np.uint32), np.asarray(host["bvh"], np.float32).view(np.uint32)), name
+        assert np.array_equal(tris.reshape(-1).view(np.uint32), np.asarray(host["triangles"], np.float32).view(np.uint32)), name
+        for stack in (64, 20):
+            ctx.set_params(max_bounces=6, stack_size=stack)
+            ctx.resize(160, 96)
+            ctx.reset_stats()
+            ctx.set_counters(True)
+            ctx.render(view, 1, 2)
+            got = ctx.read_framebuffer()
+            st = ctx.stats()
+            ctx.set_counters(False)
+            want, ost = oracle.render(host, 160, 96, view, 1, 2, max_bounces=6, stack_size=stack)
+            assert_same_bits(got, want, "%s rendered from the device-resident SAH tree, stack %d" % (name, stack))
+            for k in ("rays", "node_visits", "tri_tests", "quad_tests", "mat_fetches"):
+                assert st[k] == ost[k], (name, stack, k)
+    host = pkg.scenes.c4_scene().buffers(native=pkg.ptmi.NativeHost(), sah=True)
+    ctx.upload_scene(pkg.scenes.c4_scene().buffers_unbuilt())
+    ctx.build_scene_bvh(sah=True)
+    info = ctx.scene_bvh_info()
+    assert info["nodes"] == host["bvh"].size // 12 and info["depth"] < 40
+    _full_size_windows(ctx, oracle, host, cornell_view(pkg, "interior"), 1920, 1080, 2, dict(max_bounces=8, stack_size=40), "configs[3] from its device-built SAH tree at 1080p")
 
 
 def test_render_frame_render_ahead_is_invisible(ctx, pkg, oracle, monkeypatch):

@@ -24,8 +24,8 @@ using namespace ptmi;
 
 // csrc/ptmi_bvh_device.hip
 int ptmi_bvhdev_build_scene(void* stream, const float* d_tris, uint32_t n, const int32_t* h_meshes, int n_meshes, const float* h_xforms, int n_xforms, float* d_rows,
-                            float* d_tris_out, int* depth_out, uint32_t* bad_tri);
-int ptmi_bvhdev_make_pairs(void* stream, const float* d_rows, uint32_t nn, float* d_pairs);
+                            float* d_tris_out, int* depth_out, uint32_t* bad_tri, int sah, uint32_t* n_nodes_out);
+int ptmi_bvhdev_make_pairs(void* stream, const float* d_rows, uint32_t nn, float* d_pairs, int* d_leaf_table, uint32_t* n_multi);
 #ifdef PTMI_EXPERIMENTS
 int ptmi_diag_sort_pairs(void* stream, uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, uint32_t n);
 #endif
@@ -163,6 +163,8 @@ struct ptmi_ctx {
   DBuf d_bvh_rows;
   bool bvh_on_device = false;
   size_t bvh_dev_prims = 0;  // triangles the device-resident tree was built over
+  size_t bvh_dev_nodes = 0;  // its rows: 2 x triangles - 1 from the median builder, fewer from the SAH one (leaves of several triangles)
+  bool bvh_dev_sah = false;  // built by ptmi_build_scene_bvh_sah
   bool bvh_dev_stale = false;  // triangles / meshes / transforms were uploaded after the build: its boxes and leaf order describe another scene
   int bvh_dev_depth = 0;
   DBuf d_spheres, d_sphere_info, d_quads, d_quad_mat, d_tris, d_pretri, d_trinorm, d_meshes, d_xforms, d_mats, d_pairs, d_leaf_table;
@@ -321,7 +323,7 @@ int prepare_scene(ptmi_ctx* c) {
   if (!c->scene_dirty) return PTMI_OK;
   const int n_sph = (int)(c->h_spheres.size() / 8), n_quad = (int)(c->h_quads.size() / 20), n_tri = (int)c->n_tris_uploaded;
   const int n_mesh = (int)(c->h_meshes.size() / 4), n_xf = (int)(c->h_xforms.size() / 32), n_mat = (int)(c->h_mats.size() / 16);
-  const int n_node = c->bvh_on_device ? (int)(2 * c->bvh_dev_prims - 1) : (int)(c->h_bvh.size() / 12);
+  const int n_node = c->bvh_on_device ? (int)c->bvh_dev_nodes : (int)(c->h_bvh.size() / 12);
   char msg[256];
 
   c->has_unknown_material = false;
@@ -386,7 +388,7 @@ int prepare_scene(ptmi_ctx* c) {
   bool pairs_on_device = false;
   if (n_node > 0 && c->bvh_on_device) {
     // The tree came out of this library's own builder (ptmi_build_scene_bvh) over the triangles that are on the device: a tree by
-    // construction, every leaf one triangle of [0, n) — all that has to hold is that those triangles are still the uploaded ones.
+    // construction, its leaves a partition of the triangles [0, n) — all that has to hold is that those triangles are still the uploaded ones.
     if ((size_t)n_tri != c->bvh_dev_prims) {
       snprintf(msg, sizeof msg, "the device-resident BVH was built over %zu triangles, %d are uploaded now (build again, or upload a BVH)", c->bvh_dev_prims, n_tri);
       return fail(c, PTMI_ERR_BAD_SCENE, msg);
@@ -396,13 +398,17 @@ int prepare_scene(ptmi_ctx* c) {
     c->bvh_depth = c->bvh_dev_depth;
     const size_t n_inner = (size_t)(n_node - 1) / 2;
     HIP_TRY(c, c->d_pairs.ensure(std::max<size_t>(n_inner * 64, 16)));
-    if (n_inner) {
-      const int e = ptmi_bvhdev_make_pairs((void*)c->stream, c->d_bvh_rows.as<float>(), (uint32_t)n_node, c->d_pairs.as<float>());
+    // (a SAH tree's leaves may hold several triangles: those go through the leaf table, made on the device too — at most one entry per leaf)
+    if (c->bvh_dev_sah) HIP_TRY(c, c->d_leaf_table.ensure(std::max<size_t>(((size_t)n_node + 1) / 2 * 8, 16)));
+    {
+      uint32_t n_multi = 0;
+      const int e = ptmi_bvhdev_make_pairs((void*)c->stream, c->d_bvh_rows.as<float>(), (uint32_t)n_node, c->d_pairs.as<float>(), c->bvh_dev_sah ? c->d_leaf_table.as<int>() : nullptr, &n_multi);
       if (e) return fail(c, e == (int)hipErrorOutOfMemory ? PTMI_ERR_NO_MEMORY : PTMI_ERR_DEVICE, std::string("pair records on the device: ") + hipGetErrorString((hipError_t)e));
     }
     float r0[12];
     HIP_TRY(c, hipMemcpy(r0, c->d_bvh_rows.p, sizeof r0, hipMemcpyDeviceToHost));
-    const uint32_t rref = n_inner ? 0u : (REF_LEAF | (uint32_t)(int)r0[8]);  // the root is pair 0, or the only leaf
+    // the root is pair 0, or the only leaf (of one triangle, or — a SAH tree that never split — of several: leaf-table entry 0)
+    const uint32_t rref = n_inner ? 0u : (r0[9] == 1.0f ? (REF_LEAF | (uint32_t)(int)r0[8]) : (REF_LEAF | REF_MULTI | 0u));
     root_lo[0] = r0[0], root_lo[1] = r0[1], root_lo[2] = r0[2];
     memcpy(&root_lo[3], &rref, 4);
     root_hi[0] = r0[4], root_hi[1] = r0[5], root_hi[2] = r0[6];
@@ -540,7 +546,7 @@ int prepare_scene(ptmi_ctx* c) {
   HIP_TRY(c, up(c->d_xforms, c->h_xforms.data(), c->h_xforms.size() * 4));
   HIP_TRY(c, up(c->d_mats, c->h_mats.data(), c->h_mats.size() * 4));
   if (!pairs_on_device) HIP_TRY(c, up(c->d_pairs, pairs.data(), pairs.size() * 4));
-  HIP_TRY(c, up(c->d_leaf_table, leaf_table.data(), leaf_table.size() * 4));
+  if (!(pairs_on_device && c->bvh_dev_sah)) HIP_TRY(c, up(c->d_leaf_table, leaf_table.data(), leaf_table.size() * 4));
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // the staging vectors die at scope exit
 
   DevScene& S = c->S;
@@ -1621,7 +1627,7 @@ int ptmi_upload(ptmi_ctx* c, int which, const void* data, size_t bytes) {
 }
 
 // lib/scene.js:253-259 (create_bvh + the reordering of the triangles) on the GPU, over what is already there.
-static int build_scene_bvh_one(ptmi_ctx* c) {
+static int build_scene_bvh_one(ptmi_ctx* c, bool sah) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   const size_t n = c->n_tris_uploaded;
@@ -1644,9 +1650,9 @@ static int build_scene_bvh_one(ptmi_ctx* c) {
     return fail(c, PTMI_ERR_NO_MEMORY, std::string("ptmi_build_scene_bvh: ") + hipGetErrorString(e));
   }
   int depth = 0;
-  uint32_t bad = 0xffffffffu;
+  uint32_t bad = 0xffffffffu, n_nodes = 0;
   const int r = ptmi_bvhdev_build_scene((void*)c->stream, c->d_tris.as<float>(), (uint32_t)n, c->h_meshes.data(), n_mesh, c->h_xforms.data(), n_xf, rows.as<float>(), tris2.as<float>(),
-                                         &depth, &bad);
+                                         &depth, &bad, sah ? 1 : 0, &n_nodes);
   if (r || bad != 0xffffffffu) {
     rows.release();
     tris2.release();
@@ -1662,6 +1668,8 @@ static int build_scene_bvh_one(ptmi_ctx* c) {
   c->bvh_on_device = true;
   c->bvh_dev_stale = false;
   c->bvh_dev_prims = n;
+  c->bvh_dev_nodes = n_nodes;
+  c->bvh_dev_sah = sah;
   c->bvh_dev_depth = depth;
   c->h_bvh.clear();
   c->scene_dirty = true;
@@ -1671,7 +1679,20 @@ static int build_scene_bvh_one(ptmi_ctx* c) {
 
 int ptmi_build_scene_bvh(ptmi_ctx* c) {
   if (!c) return PTMI_ERR_INVALID_ARG;
-  return on_all_devices(c, build_scene_bvh_one, true);
+  return on_all_devices(c, [](ptmi_ctx* q) { return build_scene_bvh_one(q, false); }, true);
+}
+
+int ptmi_build_scene_bvh_sah(ptmi_ctx* c) {
+  if (!c) return PTMI_ERR_INVALID_ARG;
+  return on_all_devices(c, [](ptmi_ctx* q) { return build_scene_bvh_one(q, true); }, true);
+}
+
+int ptmi_scene_bvh_info(ptmi_ctx* c, uint64_t* n_nodes, int32_t* depth, int32_t* on_device) {
+  if (!c) return PTMI_ERR_INVALID_ARG;
+  if (n_nodes) *n_nodes = c->bvh_on_device ? (uint64_t)c->bvh_dev_nodes : (uint64_t)(c->h_bvh.size() / 12);
+  if (depth) *depth = c->bvh_on_device ? c->bvh_dev_depth : c->bvh_depth;
+  if (on_device) *on_device = c->bvh_on_device ? 1 : 0;
+  return PTMI_OK;
 }
 
 int ptmi_read_scene_buffer(ptmi_ctx* c, int which, void* dst, size_t bytes) {
@@ -1681,7 +1702,7 @@ int ptmi_read_scene_buffer(ptmi_ctx* c, int which, void* dst, size_t bytes) {
   const void* src = nullptr;
   size_t have = 0;
   if (which == PTMI_BUF_TRIANGLES) src = c->d_tris.p, have = c->n_tris_uploaded * 96;
-  else if (which == PTMI_BUF_BVH && c->bvh_on_device) src = c->d_bvh_rows.p, have = (2 * c->bvh_dev_prims - 1) * 48;
+  else if (which == PTMI_BUF_BVH && c->bvh_on_device) src = c->d_bvh_rows.p, have = c->bvh_dev_nodes * 48;
   else if (which == PTMI_BUF_BVH) {
     have = c->h_bvh.size() * 4;
     if (bytes != have) return fail(c, PTMI_ERR_INVALID_ARG, "ptmi_read_scene_buffer: byte size differs from the buffer's");

@@ -19,7 +19,7 @@ SYMBOLS = [
     "ptmi_framebuffer_device_ptr", "ptmi_bind_framebuffer", "ptmi_stream", "ptmi_resolve_rgba8", "ptmi_set_counters",
     "ptmi_set_timing", "ptmi_get_stats", "ptmi_reset_stats", "ptmi_trace", "ptmi_math_eval", "ptmi_selftest", "ptmi_build_bvh",
     "ptmi_build_bvh_sah", "ptmi_build_bvh_device", "ptmi_build_scene_bvh", "ptmi_read_scene_buffer", "ptmi_obj_parse", "ptmi_free",
-    "ptmi_device_count", "ptmi_reduce_info", "ptmi_reload_tuning",
+    "ptmi_device_count", "ptmi_reduce_info", "ptmi_reload_tuning", "ptmi_build_scene_bvh_sah", "ptmi_scene_bvh_info", "ptmi_build_bvh_sah_device",
 ]
 
 
@@ -111,6 +111,9 @@ def load_library(build=False):
     L.ptmi_build_bvh_sah.argtypes = [sz, fp, fp, i32, fp, fp, ctypes.POINTER(sz)]
     L.ptmi_build_bvh_device.argtypes = [vp, sz, fp, fp, i32, fp, fp]
     L.ptmi_build_scene_bvh.argtypes = [vp]
+    L.ptmi_build_scene_bvh_sah.argtypes = [vp]
+    L.ptmi_scene_bvh_info.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+    L.ptmi_build_bvh_sah_device.argtypes = [vp, sz, fp, fp, i32, fp, fp, ctypes.POINTER(sz)]
     L.ptmi_read_scene_buffer.argtypes = [vp, i32, fp, sz]
     L.ptmi_obj_parse.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(vp), ctypes.POINTER(sz)]
     L.ptmi_free.argtypes = [vp]
@@ -335,9 +338,27 @@ class Context:
         self._ck(self.lib.ptmi_build_bvh_device(self.h, n, _ptr(bmin), _ptr(bmax), prim_type, _ptr(nodes), _ptr(order)))
         return nodes, order
 
-    def build_scene_bvh(self):
-        """ptmi_build_scene_bvh: Scene.create_bvh() on the GPU over the uploaded (unordered) triangles, meshes and transforms; nothing comes back."""
-        self._ck(self.lib.ptmi_build_scene_bvh(self.h))
+    def build_scene_bvh(self, sah=False):
+        """ptmi_build_scene_bvh: Scene.create_bvh() on the GPU over the uploaded (unordered) triangles, meshes and transforms; nothing comes back.
+        sah=True: the reference's other builder (lib/BVH/bvhNode.js:108-283), the opt-in."""
+        self._ck((self.lib.ptmi_build_scene_bvh_sah if sah else self.lib.ptmi_build_scene_bvh)(self.h))
+
+    def scene_bvh_info(self):
+        """{nodes, depth, on_device} of the scene's BVH (ptmi_scene_bvh_info)."""
+        n, d, o = ctypes.c_uint64(), ctypes.c_int32(), ctypes.c_int32()
+        self._ck(self.lib.ptmi_scene_bvh_info(self.h, ctypes.byref(n), ctypes.byref(d), ctypes.byref(o)))
+        return {"nodes": n.value, "depth": d.value, "on_device": bool(o.value)}
+
+    def build_bvh_sah(self, bmin, bmax, prim_type=2):
+        """ptmi_build_bvh_sah_device: the binned-SAH build on this context's GPU; same result as NativeHost.build_bvh_sah."""
+        bmin = np.ascontiguousarray(bmin, np.float64)
+        bmax = np.ascontiguousarray(bmax, np.float64)
+        n = bmin.shape[0]
+        nodes = np.zeros((max(2 * n - 1, 0), 12), np.float32)
+        order = np.zeros(n, np.int64)
+        count = ctypes.c_size_t()
+        self._ck(self.lib.ptmi_build_bvh_sah_device(self.h, n, _ptr(bmin), _ptr(bmax), prim_type, _ptr(nodes), _ptr(order), ctypes.byref(count)))
+        return nodes[: count.value].copy(), order
 
     def read_scene_buffer(self, which, count):
         """Test hook: the context's triangles ('triangles', count = number of triangles) or BVH rows ('bvh', count = number of nodes) as an array."""
