@@ -56,6 +56,9 @@ FETCH_MULT = {"k_bvh": 1.0}  # bytes per FETCH_SIZE byte, calibrated per access 
 GATHER_PEAK_RECORDS_PER_S = 223.5e9  # fallback; gather_peak() reads the probe's file
 GUIDE_MAX_CLOCK_GHZ = 2.4  # MI355X_MICROARCH.md "Max clock"
 N_CUS = 256
+# Is there a counter that tells DRAM from Infinity-Cache (MALL) traffic?  `rocprofv3 --list-avail` on the MI355X box (gfx950, ROCm 7.2) was searched for MALL / HBM / DRAM /
+# EA_*DRAM names in round 5 (profiles/r05_list_avail_mall.txt): see MALL_NOTE's text for what it offers.
+MALL_NOTE = "not separated: see profiles/r05_list_avail_mall.txt"
 
 
 def gather_peak():
@@ -301,9 +304,12 @@ def kernel_table(split, steps_in_split, pmc, shade_variant=None):
             # record gathers (tools/fetch_calib.hip on an 8 GiB table, profiles/fetch_calib.json: stream 2.000, gather 1.000, stores 1.000).
             # k_bvh's reads are record gathers plus a thin flag scan; the other kernels stream their state.
             mult = FETCH_MULT.get(k, 2.0)
-            e["hbm_bytes_per_launch"] = mult * fb + wb
-            e["hbm_bytes_per_launch_if_all_reads_were_streams"] = 2.0 * fb + wb
-            e["hbm_frac"] = e["hbm_bytes_per_launch"] / (ms / n * 1e-3) / (HBM_PEAK_GBS * 1e9) if n and ms else None
+            # FETCH_SIZE / WRITE_SIZE count at the L2 <-> fabric boundary: reads the Infinity Cache (MALL) serves are in them (MI355X_MICROARCH.md, HBM), so these
+            # are FABRIC bytes — an upper bound on DRAM bytes; for a scene that fits the 256 MB MALL (every BASELINE configuration's digests) the DRAM share of
+            # k_bvh's gathers is far smaller.  `fabric_frac_of_hbm_peak` divides them by the 8 TB/s HBM peak all the same: it can only over-state how HBM-bound a kernel is.
+            e["fabric_bytes_per_launch"] = mult * fb + wb
+            e["fabric_bytes_per_launch_if_all_reads_were_streams"] = 2.0 * fb + wb
+            e["fabric_frac_of_hbm_peak"] = e["fabric_bytes_per_launch"] / (ms / n * 1e-3) / (HBM_PEAK_GBS * 1e9) if n and ms else None
         tab[k] = e
     return tab
 
@@ -313,9 +319,10 @@ def roofline_of(tab, dom, timed_ms_per_launch, timed_launches, gather_records_pe
     the kernel's own instruction mix against 1024 SIMDs at the guide's 2.4 GHz), HBM (measured fabric bytes / 8 TB/s) or — k_bvh — the L1 gather
     path (64-byte records fetched per second / the rate tools/gather_probe.hip measures for that access pattern, at 2.4 GHz)."""
     e = tab[dom]
-    vf, hf = e.get("valu_busy_frac_at_2p4_ghz"), e.get("hbm_frac")
+    vf, hf = e.get("valu_busy_frac_at_2p4_ghz"), e.get("fabric_frac_of_hbm_peak")
     r = {"kernel": dom, "avg_launch_ms": timed_ms_per_launch, "launches": timed_launches, "share_of_kernel_time": e["share_of_kernel_time"],
-         "traffic": e.get("hbm_bytes_per_launch")}
+         "traffic": e.get("fabric_bytes_per_launch"),
+         "traffic_is": "bytes per launch over the fabric (2 x FETCH_SIZE for streams, 1 x for 64-byte gathers, + WRITE_SIZE: profiles/fetch_calib.json), Infinity-Cache hits included"}
     gf = None
     gpeak, gcpr, gsrc = gather_peak()
     if dom == "k_bvh" and gather_records_per_launch and timed_ms_per_launch:
@@ -339,7 +346,7 @@ def roofline_of(tab, dom, timed_ms_per_launch, timed_launches, gather_records_pe
                                      "k_bvh: its rate per node visit does not move with the scene's size from 1 MB to 134 MB of digests (profiles/r03_size_sweep.txt) nor with "
                                      "occupancy from 18 to 26 waves per CU (DESIGN.md §4)" % (gcpr, gpeak / 1e9, gsrc)})
     elif hf is not None and hf == best:
-        gbs = e["hbm_bytes_per_launch"] / (timed_ms_per_launch * 1e-3) / 1e9
+        gbs = e["fabric_bytes_per_launch"] / (timed_ms_per_launch * 1e-3) / 1e9
         r.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
     else:
         rate = e["valu_instr_per_launch"] / (timed_ms_per_launch * 1e-3) / 1e9
@@ -353,7 +360,7 @@ def roofline_of(tab, dom, timed_ms_per_launch, timed_launches, gather_records_pe
                   "peak_definition": "1024 SIMDs x 2.4 GHz / (average issue cycles per wave64 instruction of this kernel = %.2f)" % (e.get("avg_cycles_per_valu_instr") or 0.0)})
     if max(vf or 0.0, hf or 0.0, gf or 0.0) < 0.5:
         r["bound_note"] = "no resource is busy half the time: the kernel waits on memory latency (wave_wait_frac %.2f)" % (e.get("wave_wait_frac") or 0.0)
-    r["valu_busy_frac_at_2p4_ghz"], r["hbm_frac"], r["l1_gather_frac"] = vf, hf, gf
+    r["valu_busy_frac_at_2p4_ghz"], r["fabric_frac_of_hbm_peak"], r["l1_gather_frac"] = vf, hf, gf
     for k in ("valu_busy_frac_at_pass_clock", "valu_busy_frac_upper_bound_at_pass_clock", "rocprof_valu_busy", "rocprof_valu_utilization", "lane_weighted_frac_at_2p4_ghz",
               "clock_ghz_in_pmc_pass", "cost_model"):
         if e.get(k) is not None:
@@ -407,9 +414,12 @@ def measure(pkg, torch, pdist, ctx, wl, spp, steps, warmup, reduce_fn):
         torch.cuda.synchronize()
     pdist.barrier()
     coll[0] = 0.0
+    step_ms = []
     t0 = time.perf_counter()
     for _ in range(steps):
-        step()
+        ts = time.perf_counter()
+        step()  # (ends with ctx.synchronize(): the step's wall time)
+        step_ms.append((time.perf_counter() - ts) * 1e3)
     ctx.synchronize()
     if torch is not None:
         torch.cuda.synchronize()
@@ -426,7 +436,7 @@ def measure(pkg, torch, pdist, ctx, wl, spp, steps, warmup, reduce_fn):
     cst = ctx.stats()
     ctx.set_counters(False)
     assert cst["rays"] * steps == st["rays"], "ray count differs between the counted and the timed pass"
-    return {"dt": dt, "st": st, "split": split, "cst": cst, "dom": dom, "collective_ms_per_step": coll_ms}
+    return {"dt": dt, "st": st, "split": split, "cst": cst, "dom": dom, "collective_ms_per_step": coll_ms, "step_ms": step_ms}
 
 
 def measure_short(torch, pdist, ctx, wl, spp, steps, reduce_fn):
@@ -472,7 +482,8 @@ def cpu_baseline(pkg, wl, spp, args):
         _, ost = ptm_oracle.render(buffers, W, H, view, 1, frames, threads=threads, pixel_range=pr, **kw)
         cdt = time.perf_counter() - t
         what = "same scene and camera, %dx%d%s, frames 1..%d of %d (%d rays), scalar f32 oracle%s" % (
-            W, H, "" if rows >= H else ", pixel rows 0..%d" % (rows - 1), frames, spp, ost["rays"], " with OpenMP over pixels" if threads > 1 else ", one thread")
+            W, H, "" if rows >= H else ", pixel rows 0..%d" % (rows - 1), frames, spp, ost["rays"],
+            " with OpenMP over pixels on %d of the box's %d logical CPUs (--cpu-threads: a 1-GPU box's CPU share)" % (threads, os.cpu_count() or 0) if threads > 1 else ", one thread")
         return ost["rays"] / cdt / 1e6, what
 
     v, what = sample(cores, args.cpu_seconds, H)
@@ -548,13 +559,81 @@ def main():
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"], help="auto = rocprofv3 --pmc passes over the workload before the timed run (N = 1 only)")
     ap.add_argument("--pmc-timeout", type=float, default=240.0)
     ap.add_argument("--extra-configs", default="auto", choices=["auto", "off"], help="auto = append the configs[2] (871k-triangle) run to the line (N = 1, default workload only)")
+    ap.add_argument("--c3-steps", type=int, default=6, help="timed steps of the appended configs[2] leg (the line carries their median and min-max)")
+    ap.add_argument("--c3-warmup", type=int, default=2)
+    ap.add_argument("--host-collective", action="store_true",
+                    help="one process per GPU: the step's collective over gloo on host copies of the framebuffers instead of RCCL (every rank keeps its own GPU) — "
+                         "what the watchdog falls back to when the RCCL run hangs or dies")
+    ap.add_argument("--watchdog-seconds", type=float, default=300.0,
+                    help="N > 1: the measurement runs in a fresh child process (started before this one touches the GPU); a child that has not delivered within this many "
+                         "seconds is killed and ONE more fresh child runs the fall-back (in-library: PTMI_MULTI_REDUCE=copy; one process per GPU: --collective gather "
+                         "--host-collective); its line says FALLBACK in config.parallelism.  0 = no watchdog (measure in this process)")
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--attempt", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--fallback-reason", default="", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.pmc_child:
         pmc_child(args)
         return
+    multi = int(os.environ.get("WORLD_SIZE", "1")) > 1 or bool(args.devices) or max(args.gpus, 1) > 1
+    if multi and not args.worker and args.watchdog_seconds > 0:
+        sys.exit(watchdog(args))
+    worker(args)
 
+
+def watchdog(args):
+    """N > 1: the first contact with RCCL on a new node must not be able to lose the record.  This process never touches the GPU (no torch, no HIP): it starts the
+    measurement as a fresh child — same arguments and environment plus --worker — and relays its line.  A child that dies, or has not finished within
+    --watchdog-seconds (the usual first-contact failure is a hang inside communicator initialisation), is killed by its process group and ONE more fresh child
+    runs the fall-back: the in-library context with PTMI_MULTI_REDUCE=copy (peer copies + add kernel instead of ncclReduce), the one-process-per-GPU driver with
+    --collective gather --host-collective (gloo on host copies, a new rendezvous port).  Under torch.distributed.run every rank's parent does this on its own; the
+    limits are the same, so the ranks arrive at the fall-back together."""
+    import signal
+
+    rank = int(os.environ.get("RANK", "0"))
+    launched = int(os.environ.get("WORLD_SIZE", "1")) > 1
+    argv = [a for a in sys.argv[1:]]
+    why = ""
+    for attempt in (0, 1):
+        env = dict(os.environ)
+        extra = ["--worker", "--attempt", str(attempt)]
+        if attempt == 1:
+            extra += ["--fallback-reason", why]
+            if launched:
+                extra += ["--collective", "gather", "--host-collective"]
+                env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 1)  # the first rendezvous' store died with rank 0's child
+            else:
+                env["PTMI_MULTI_REDUCE"] = "copy"
+        t0 = time.perf_counter()
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + extra, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            out, _ = p.communicate(timeout=args.watchdog_seconds)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)  # the child's own session: exactly the processes it started
+            except ProcessLookupError:
+                pass
+            out, _ = p.communicate()
+            why = "attempt %d produced no line within %.0f s (killed)" % (attempt, args.watchdog_seconds)
+            print("bench.py watchdog (rank %d): %s" % (rank, why), file=sys.stderr, flush=True)
+            continue
+        lines = [l for l in (out or "").splitlines() if l.startswith("{")]
+        if p.returncode == 0 and (lines or rank != 0):
+            for l in lines:
+                print(l, flush=True)
+            return 0
+        why = "attempt %d exited with code %d after %.0f s" % (attempt, p.returncode, time.perf_counter() - t0)
+        print("bench.py watchdog (rank %d): %s" % (rank, why), file=sys.stderr, flush=True)
+    return 1
+
+
+def worker(args):
+    if args.attempt == 0 and os.environ.get("PTMI_BENCH_SIMULATE") == "hang":  # (tests/test_bench_dist_gpu.py: the watchdog's rehearsal)
+        time.sleep(1e6)
+    if args.attempt == 0 and os.environ.get("PTMI_BENCH_SIMULATE") == "crash":
+        os._exit(3)
     rank_env, world_env = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     # Three ways to run.  (a) one GPU.  (b) N > 1 under torch.distributed.run (WORLD_SIZE set: how the driver launches it): one process per GPU,
     # torch.distributed's reduce over RCCL.  (c) N > 1 WITHOUT a launcher (`python bench.py --gpus N`, or --devices): ONE process, ONE context over
@@ -577,11 +656,13 @@ def main():
 
     pkg = entry._load_pkg()
     torch = None
+    host_coll = False
     if world_env > 1:
         import torch
         from webgpu_path_tracer_amd import dist as pdist
 
-        rank, world, local = pdist.init_process_group("gloo" if args.rehearse_gloo else None)
+        host_coll = args.rehearse_gloo or args.host_collective
+        rank, world, local = pdist.init_process_group("gloo" if host_coll else None)
         if args.rehearse_gloo:
             local = 0
         if world != max(args.gpus, 1):
@@ -611,7 +692,7 @@ def main():
                     pdist.reduce_framebuffer(t, 0)
 
             def reduce_fn():
-                if args.rehearse_gloo:
+                if host_coll:
                     host = fb_t.cpu()
                     collective(host)
                     fb_t.copy_(host)
@@ -650,16 +731,18 @@ def main():
             tab["k_bvh"]["records_per_launch"] = gather
         # What SURVEY §8d's yardstick calls waste: HBM bytes the step moves beyond what the reference's megakernel must move — its framebuffer read-modify-write
         # once per frame (32 B per pixel and frame) and the scene once.  The wavefront design pays the rest as path state crossing HBM between kernels.
-        if any(tab[k].get("hbm_bytes_per_launch") is not None for k in KERNELS):  # (a kernel the batch never launched has no counters and moved nothing)
-            step_bytes = sum((tab[k].get("hbm_bytes_per_launch") or 0.0) * tab[k]["launches_per_step"] for k in KERNELS)
+        if any(tab[k].get("fabric_bytes_per_launch") is not None for k in KERNELS):  # (a kernel the batch never launched has no counters and moved nothing)
+            step_bytes = sum((tab[k].get("fabric_bytes_per_launch") or 0.0) * tab[k]["launches_per_step"] for k in KERNELS)
             scene_bytes = sum(np.asarray(wl["buffers"][k]).nbytes for k in ("spheres", "quads", "triangles", "meshes", "transforms", "materials", "bvh"))
             compulsory = 32.0 * wl["W"] * wl["H"] * spp / max(world, 1) + scene_bytes
-            roof["step_hbm_bytes"] = step_bytes
+            roof["step_fabric_bytes"] = step_bytes
             roof["compulsory_bytes"] = compulsory
             roof["state_traffic_bytes"] = step_bytes - compulsory
             roof["state_over_compulsory"] = (step_bytes - compulsory) / compulsory if compulsory else None
-            roof["step_hbm_frac"] = step_bytes / (dt / steps) / (HBM_PEAK_GBS * 1e9)
-            roof["traffic_note"] = ("step_hbm_bytes = measured fabric bytes of all kernels of one step (this run's FETCH_SIZE / WRITE_SIZE passes); compulsory_bytes = the reference "
+            roof["step_fabric_frac_of_hbm_peak"] = step_bytes / (dt / steps) / (HBM_PEAK_GBS * 1e9)
+            roof["dram_vs_mall"] = MALL_NOTE
+            roof["traffic_note"] = ("step_fabric_bytes = measured fabric bytes of all kernels of one step (this run's FETCH_SIZE / WRITE_SIZE passes: Infinity-Cache hits count, "
+                                    "so DRAM bytes are at most this); compulsory_bytes = the reference "
                                     "megakernel's own HBM need (framebuffer RMW per pixel and frame + the scene once); the difference is wavefront path state (queues, hit "
                                     "records, per-path radiance) that the reference never moves — waste by SURVEY §8d's yardstick, the price of compaction and lane refill")
         hit_scene_gbs = alg_bytes(cst) / (m["split"]["render_ms"] / 1e3) / 1e9 if m["split"]["render_ms"] > 0 else None
@@ -668,6 +751,8 @@ def main():
         roof["kernels"] = tab
         return {
             "value": rays / dt / 1e6, "ms_per_step": dt / steps * 1e3, "rays_per_step": rays / steps, "mpaths_per_s": paths / dt / 1e6,
+            "ms_per_step_stats": {"median": float(np.median(m["step_ms"])), "min": float(np.min(m["step_ms"])), "max": float(np.max(m["step_ms"])), "steps": len(m["step_ms"]),
+                                  "note": "this rank's wall time of each timed step; `ms_per_step` = the whole timed region / steps"},
             "workload": "%s, %dx%d, %d spp%s, %d bounces, stack_size %d%s" % (
                 wl["label"], wl["W"], wl["H"], spp,
                 ("" if world == 1 else " (weak scaling: %d per GPU x %d GPUs, every GPU traces 1/%d of the pixels for all of them)" % (per, world, world) if args.scaling == "weak"
@@ -687,6 +772,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": d["ms_per_step"],
+            "ms_per_step_stats": d["ms_per_step_stats"],
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
@@ -698,15 +784,16 @@ def main():
                 "mpaths_per_s": d["mpaths_per_s"],
                 "parallelism": ("ptmi_create_multi x%d (one process, one context; devices %s); the step's collective inside the library: %s%s" % (
                     world, ",".join(map(str, devices)), m["reduce_info"], "" if len(set(devices)) == len(devices) else "; REHEARSAL: shards share a GPU") if inlib
-                    else ("pixel tiles x%d (one process per GPU) + 1 RCCL %s per step (torch.distributed%s)" % (
-                        world, "reduce of the full accumulation buffers" if args.collective == "reduce" else "gather of every rank's own tiles", "; REHEARSAL over gloo on host copies" if args.rehearse_gloo else ""))
-                    if world > 1 else "1 GPU"),
+                    else ("pixel tiles x%d (one process per GPU) + 1 %s %s per step (torch.distributed%s)" % (
+                        world, "gloo (host copies)" if host_coll else "RCCL", "reduce of the full accumulation buffers" if args.collective == "reduce" else "gather of every rank's own tiles",
+                        "; REHEARSAL: the ranks share cuda:0" if args.rehearse_gloo else ""))
+                    if world > 1 else "1 GPU") + ("; FALLBACK after the first attempt failed: %s" % args.fallback_reason if args.fallback_reason else ""),
             },
             "roofline": d["roofline"],
         }
         if world > 1:
             out["config"]["collective_ms_per_step"] = m["collective_ms_per_step"]  # rank 0's wall time inside the collective, its wait for the slowest rank included
-            out["config"]["collective_bytes_into_root"] = (world - 1) * wl["W"] * wl["H"] * 16 // (1 if (inlib or args.collective == "reduce") else world)
+            out["config"]["collective_bytes_into_root"] = (world - 1) * wl["W"] * wl["H"] * 16 // (world if ((inlib and m["reduce_mode"] == 4) or (not inlib and args.collective == "gather")) else 1)
             o = m["other"]
             out["config"]["other_scaling"] = {"scaling": o["scaling"], "spp_total": o["spp"], "steps": o["steps"], "value": o_rays / o_dt / 1e6, "unit": "Mrays/s",
                                               "ms_per_step": o_dt / o["steps"] * 1e3, "note": "informational: the same ranks and collective in the other scaling mode; `value` above is --scaling %s" % args.scaling}
@@ -747,8 +834,9 @@ def main():
             out["config"]["two_shards_on_one_gpu"] = {"error": str(e)[:200]}
         setup = {args.workload: wl["setup"]}
         if extra_c3:
-            wl3, ctx3, spp3, per3, m3 = run_workload("c3", 2, 1, 0)
-            d3 = describe(wl3, spp3, per3, m3, 2, m3["st"]["rays"], m3["st"]["paths"], m3["dt"], pmc.get("c3"))
+            wl3, ctx3, spp3, per3, m3 = run_workload("c3", args.c3_steps, args.c3_warmup, 0)
+            d3 = describe(wl3, spp3, per3, m3, args.c3_steps, m3["st"]["rays"], m3["st"]["paths"], m3["dt"], pmc.get("c3"))
+            d3["steps"], d3["warmup"] = args.c3_steps, args.c3_warmup
             # the reference's own dragon figure (benchmarks.txt:18-20) is paths/s at its canvas size; both readings of north_star's ">= 10x"
             d3["vs_baseline"] = d3["mpaths_per_s"] / REF_DRAGON_MPATHS
             d3["vs_baseline_basis"] = ("Mpaths/s / 33.5 Mpaths/s = the reference's 62 fps x 900x600 px on its 297,972-triangle dragon (benchmarks.txt:18-20; hardware, "

@@ -104,7 +104,9 @@ typedef struct ptmi_stats {
   /* API v4 */
   uint64_t reduce_mode;  /* how this context sums its devices' accumulation buffers (ptmi_create_multi): 0 = single device, nothing to sum;
                           * 1 = ncclReduce (RCCL over xGMI); 2 = peer copies + add kernel (shards share a GPU, or PTMI_MULTI_REDUCE=copy);
-                          * 3 = peer copies + add kernel as a FALLBACK after librccl failed to load / initialise / reduce (ptmi_reduce_info says why) */
+                          * 3 = peer copies + add kernel as a FALLBACK after librccl failed to load / initialise / reduce (ptmi_reduce_info says why);
+                          * 4 (API v5, the default of a multi-device context) = tile gather: every device's own tiles copied into place on the first device, 1/N of the
+                          * bytes of a full-buffer reduce and no arithmetic (PTMI_MULTI_REDUCE=rccl / copy select 1 / 2) */
   uint64_t peer_links;   /* directed root<->peer device pairs with hipDeviceEnablePeerAccess in force */
   uint64_t placement_sets; /* queue-array sets the last placement search timed (0 = none ran; ensure_paths) */
   double placement_ms;   /* host time that search added to the render that allocated the path buffers */
@@ -130,9 +132,10 @@ const char* ptmi_last_error(const ptmi_ctx* ctx);
 int ptmi_create(ptmi_ctx** out, int device_id);
 /* The same for n_devices GPUs of this node behind ONE context: every call below is applied to all of them
  * (uploads are replicated, renders run concurrently, one stream per GPU); the pixel tiles of this context's shard are
- * dealt round-robin to the devices, and ptmi_read_framebuffer / ptmi_resolve_rgba8 first sum the per-device accumulation
- * buffers into a gather buffer on device_ids[0] — one ncclReduce (f32 sum, W*H*4 values) over xGMI through librccl, loaded
- * on first use — so the caller sees one image, bit-identical to the single-GPU one.  The reference's caller
+ * dealt round-robin to the devices, and ptmi_read_framebuffer / ptmi_resolve_rgba8 first assemble the per-device accumulation
+ * buffers in a gather buffer on device_ids[0] — by default every device's OWN tiles are read into place over xGMI (peer access; 1/N of
+ * the bytes, no arithmetic); with PTMI_MULTI_REDUCE=rccl one ncclReduce of the full buffers (f32 sum, W*H*4 values) through librccl,
+ * loaded on first use — so the caller sees one image, bit-identical to the single-GPU one.  The reference's caller
  * (renderer.js:91-124,184-191) needs no change.  A device id may be listed more than once (its shards then share that
  * GPU and are summed by a kernel instead: how the multi-device path is tested on a one-GPU box). */
 int ptmi_create_multi(ptmi_ctx** out, const int* device_ids, int n_devices);

@@ -41,6 +41,13 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
+def hooks(pkg):
+    """The tests' own build of the library (-DPTMI_TEST_HOOKS: PTMI_TEST_ALLOC_LIMIT, PTMI_TEST_RCCL_FAIL — fault injection the product build does not
+    carry), loaded NEXT TO the product library: Context(..., lib=hooks).  Built by __graft_entry__.build()."""
+    return pkg.ptmi.load_library(path=pkg._build.TESTHOOKS_LIB)
+
+
+@pytest.fixture(scope="session")
 def ctx(pkg):
     """One device context for the whole GPU session.  No skip: on a GPU box a missing library or
     device must FAIL the gpu-marked tests."""

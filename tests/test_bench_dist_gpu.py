@@ -72,12 +72,12 @@ def test_bench_line_contract_with_its_own_pmc_passes():
         assert roof["bound"] in ("valu_issue", "hbm", "l1_gather") and 0 < roof["frac"] < 1.25
         assert roof["traffic"] > 0 and "rocprofv3 --pmc passes made by this run" in roof["pmc_source"]
         assert "valu_busy_frac_at_2p4_ghz" in tab[roof["kernel"]]
-        for k in ("step_hbm_bytes", "compulsory_bytes", "state_traffic_bytes"):
+        for k in ("step_fabric_bytes", "compulsory_bytes", "state_traffic_bytes"):
             assert roof[k] == roof[k] and roof[k] is not None, k
         assert roof["compulsory_bytes"] >= 32 * 640 * 360 * 8
         for v in tab.values():
             if "valu_busy_frac_at_2p4_ghz" in v:  # (a batch this small is k_generate + k_tail + k_accumulate: the per-bounce kernels are never launched)
-                assert 0 <= v["valu_busy_frac_at_2p4_ghz"] < 1.25 and 0 <= v["hbm_frac"] < 1.25 and 0 < v["active_lane_frac"] <= 1
+                assert 0 <= v["valu_busy_frac_at_2p4_ghz"] < 1.25 and 0 <= v["fabric_frac_of_hbm_peak"] < 1.25 and 0 < v["active_lane_frac"] <= 1
                 assert v["rocprof_valu_busy"] > 0 and v["valu_busy_frac_at_pass_clock"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["single_thread"]["cores"] == 1 and cb["single_thread"]["value"] > 0
@@ -100,7 +100,7 @@ def test_bench_in_library_multi_device_path_without_a_launcher():
     assert len(lines) == 1
     b = json.loads(lines[0])
     assert b["n_gpus"] == 2 and b["scaling"] == "strong" and b["metric"] == a["metric"] and b["value"] > 0
-    assert "ptmi_create_multi x2" in b["config"]["parallelism"] and "add kernel (shards share a GPU)" in b["config"]["parallelism"]
+    assert "ptmi_create_multi x2" in b["config"]["parallelism"] and "tile gather" in b["config"]["parallelism"]
     assert b["config"]["other_scaling"]["scaling"] == "weak"
     assert b["config"]["rays_per_step"] == a["config"]["rays_per_step"]  # the same 4 frames, pixel tiles dealt to the two shards
     # weak scaling (the default): spp x 2
@@ -111,3 +111,34 @@ def test_bench_in_library_multi_device_path_without_a_launcher():
     # asking for more GPUs than the box has fails loudly (the driver must see it), it does not fall back to one
     bad = subprocess.run([sys.executable, "bench.py", "--gpus", "64"] + common, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert bad.returncode != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("how", ["hang", "crash"])
+def test_bench_watchdog_falls_back_when_the_first_attempt_hangs_or_dies(how):
+    """The first contact with RCCL on an 8-GPU node must not be able to lose the record: for N > 1 bench.py measures in a fresh child
+    process; when that child hangs (PTMI_BENCH_SIMULATE=hang: it sleeps forever) or dies (=crash), the parent — which never touched the GPU — kills it by its
+    process group and starts ONE more fresh child with the fall-back collective; the line it prints says FALLBACK and why.  In-library driver on one GPU
+    (--devices 0,0) and the one-process-per-GPU driver (two ranks under torch.distributed.run, gloo rehearsal)."""
+    common = ["--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--pmc", "off", "--extra-configs", "off", "--width", "320", "--height", "180", "--spp", "4", "--watchdog-seconds", "60"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PTMI_BENCH_SIMULATE=how)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--devices", "0,0"] + common, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    par = d["config"]["parallelism"]
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "FALLBACK after the first attempt failed" in par, par
+    assert ("no line within 60 s" in par) if how == "hang" else ("exited with code 3" in par), par
+    assert "watchdog" in r.stderr
+    if how == "crash":  # (the hang costs a minute per driver: once is enough)
+        two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+                              "bench.py", "--gpus", "2", "--rehearse-gloo"] + common, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert two.returncode == 0, two.stderr[-2000:]
+        lines = [l for l in two.stdout.strip().splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        b = json.loads(lines[0])
+        par = b["config"]["parallelism"]
+        assert b["n_gpus"] == 2 and "FALLBACK after the first attempt failed" in par and "gather of every rank's own tiles" in par and "gloo" in par, par

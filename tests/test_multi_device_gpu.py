@@ -1,7 +1,8 @@
 """ptmi_create_multi: one context over several GPUs — tiles of the caller's shard dealt round-robin to the local devices, ONE
-reduce of the accumulation buffers inside ptmi_read_framebuffer (ncclReduce over xGMI when every shard has its own GPU).
-A one-GPU box can list device 0 several times: the shards then share the GPU and are summed by a kernel; the RCCL library
-itself is exercised with a one-rank communicator (PTMI_MULTI_REDUCE=rccl)."""
+collective inside ptmi_read_framebuffer: by default the tile gather (every device's own tiles read into place on the first device: 1/N of
+the bytes, no arithmetic), PTMI_MULTI_REDUCE=rccl the ncclReduce of the full buffers over xGMI, =copy peer copies + an add kernel.
+A one-GPU box can list device 0 several times: the shards then share the GPU; the RCCL library itself is exercised with a one-rank
+communicator (PTMI_MULTI_REDUCE=rccl)."""
 import numpy as np
 import pytest
 
@@ -30,16 +31,25 @@ def _render(pkg, devices, b, view, w, h, frames, **params):
         ctx.render(view, 1, frames)
         fb = ctx.read_framebuffer()
         st = ctx.stats()
+        st["reduce_info"] = ctx.reduce_info()
         px = ctx.resolve_rgba8(frames)
     return fb, st, px
 
 
-@pytest.mark.parametrize("n", [2, 3, 8])
-def test_shards_in_one_context_equal_single_device(pkg, oracle, n):
+@pytest.mark.parametrize("n,mode", [(2, None), (3, None), (8, None), (3, "copy"), (8, "copy")])
+def test_shards_in_one_context_equal_single_device(pkg, oracle, monkeypatch, n, mode):
+    """... through the tile gather (the default: reduce_mode 4, the devices' own tiles put side by side) and through the peer-copy + add reduce."""
     b = pkg.scenes.golden_buffers("default")  # spheres, fog volumes, quads, a cube mesh
     view = cornell_view(pkg, "default") if "default" in pkg.scenes.CAMERAS else cornell_view(pkg)
     one, st1, px1 = _render(pkg, 0, b, view, 200, 120, 6, max_bounces=6)
+    if mode:
+        monkeypatch.setenv("PTMI_MULTI_REDUCE", mode)
+    else:
+        monkeypatch.delenv("PTMI_MULTI_REDUCE", raising=False)
     many, stn, pxn = _render(pkg, [0] * n, b, view, 200, 120, 6, max_bounces=6)
+    assert stn["reduce_mode"] == (2 if mode else 4) and (("tile gather" in stn["reduce_info"]) == (mode is None)), stn["reduce_info"]
+    if not mode:
+        assert "0.0 MB between GPUs" in stn["reduce_info"]  # (the shards share the GPU: nothing crosses a link)
     assert_same_bits(many, one, "%d shards in one context" % n)
     assert np.array_equal(px1, pxn)
     for k in ("rays", "paths", "node_visits", "tri_tests", "sphere_tests", "quad_tests", "mat_fetches"):
@@ -108,17 +118,20 @@ def test_rccl_library_one_rank_communicator(pkg, oracle, monkeypatch):
         pkg.Context([0, 0])
 
 
-@pytest.mark.parametrize("where", ["init", "reduce"])
-def test_rccl_failure_falls_back_to_the_peer_copy_reduce(pkg, oracle, monkeypatch, where):
+@pytest.mark.parametrize("where", ["init", "reduce", "mid"])
+def test_rccl_failure_falls_back_to_the_peer_copy_reduce(pkg, hooks, oracle, monkeypatch, where):
     """The RCCL path must be able to fail without taking the render with it (ncclReduce with N > 1 has never run on hardware):
-    when ncclCommInitAll fails the context is created all the same, when the reduce's group fails the read-back succeeds all the same — both
+    when ncclCommInitAll fails the context is created all the same, when the reduce's group fails — at its start, or in the middle, after a
+    ncclReduce has been enqueued: the communicators are then aborted before anybody waits for a stream — the read-back succeeds all the same, both
     through the peer-copy + add reduce, bit-identical, and the context says so (stats.reduce_mode 3, ptmi_reduce_info "FALLBACK: ...").
-    PTMI_TEST_RCCL_FAIL simulates the two failures on a box where RCCL works."""
+    PTMI_TEST_RCCL_FAIL (the tests' build of the library only) simulates the failures on a box where RCCL works."""
     monkeypatch.setenv("PTMI_MULTI_REDUCE", "rccl")
     monkeypatch.setenv("PTMI_TEST_RCCL_FAIL", where)
     b = pkg.scenes.golden_buffers("c1")
     view = cornell_view(pkg)
-    with pkg.Context([0]) as ctx:
+    with pkg.Context([0]) as ctx:  # the product build does not know the variable
+        assert ctx.stats()["reduce_mode"] == 1 and "ncclReduce" in ctx.reduce_info()
+    with pkg.Context([0], lib=hooks) as ctx:
         assert ctx.stats()["reduce_mode"] == (3 if where == "init" else 1)
         ctx.upload_scene(b)
         ctx.set_params(max_bounces=4)
@@ -135,19 +148,19 @@ def test_rccl_failure_falls_back_to_the_peer_copy_reduce(pkg, oracle, monkeypatc
     assert_same_bits(mid, want2, "first read-back, through the fall-back")
     assert_same_bits(fb, want3, "second read-back")
     monkeypatch.delenv("PTMI_TEST_RCCL_FAIL")
-    with pkg.Context([0]) as ctx:  # (the simulated failure is per context creation: RCCL itself is intact)
+    with pkg.Context([0], lib=hooks) as ctx:  # (the simulated failure belongs to the context it was created with: RCCL itself is intact)
         assert ctx.stats()["reduce_mode"] == 1 and "ncclReduce" in ctx.reduce_info()
 
 
 def test_two_real_devices_in_one_context(pkg, oracle, monkeypatch):
-    """The in-library multi-GPU path on devices [0, 1]: ncclCommInitAll over two GPUs and ncclReduce with two ranks (then the same through the
-    peer-copy reduce), against the oracle.  Needs two visible GPUs — the builder's box has one; the driver's multi-GPU node runs it."""
+    """The in-library multi-GPU path on devices [0, 1]: the tile gather over peer access, then ncclCommInitAll over two GPUs and ncclReduce with two
+    ranks, then the peer-copy reduce, against the oracle.  Needs two visible GPUs — the builder's box has one; the driver's multi-GPU node runs it."""
     if pkg.load_library().ptmi_device_count() < 2:
         pytest.skip("one GPU visible: the two-device communicator cannot be built here")
     b = pkg.scenes.golden_buffers("c2m")
     view = cornell_view(pkg)
     want, ost = oracle.render(b, 192, 108, view, 1, 4, max_bounces=6)
-    for mode, expect in ((None, 1), ("copy", 2)):
+    for mode, expect in ((None, 4), ("rccl", 1), ("copy", 2)):
         if mode:
             monkeypatch.setenv("PTMI_MULTI_REDUCE", mode)
         else:

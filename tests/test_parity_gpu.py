@@ -673,15 +673,15 @@ def test_render_frame_render_ahead_is_invisible(ctx, pkg, oracle, monkeypatch):
     assert_same_bits(ctx.read_framebuffer(), expect(range(30, 40), v2, max_bounces=3), "after clear")
 
 
-def test_auto_batch_shrinks_when_memory_is_short(pkg, oracle, monkeypatch):
+def test_auto_batch_shrinks_when_memory_is_short(pkg, hooks, oracle, monkeypatch):
     """With the automatic frames-in-flight budget, an allocation failure halves the batch instead of failing the render
-    (PTMI_TEST_ALLOC_LIMIT turns every device allocation above 256 MB into a hipMalloc that really fails — 2^60 bytes —, so the HIP
+    (PTMI_TEST_ALLOC_LIMIT — in the tests' build of the library — turns every device allocation above 256 MB into a hipMalloc that really fails — 2^60 bytes —, so the HIP
     runtime's error state is what a real out-of-memory leaves behind: 512 frames of 256x256 need 600 MB per state array,
     so the batch shrinks 512 -> 256 -> 128).  Same image as always; an explicit frames_in_flight still fails loudly."""
     monkeypatch.setenv("PTMI_TEST_ALLOC_LIMIT", str(256 << 20))
     b = pkg.scenes.golden_buffers("c1")
     view = cornell_view(pkg)
-    with pkg.Context(0) as ctx:
+    with pkg.Context(0, lib=hooks) as ctx:
         ctx.upload_scene(b)
         ctx.set_params(max_bounces=3)
         ctx.resize(256, 256)
@@ -713,14 +713,14 @@ def test_placement_search_is_invisible(pkg, monkeypatch):
     assert results[0][1] == results[1][1]
 
 
-def test_failed_triangle_reupload_keeps_the_old_scene(pkg, oracle, monkeypatch):
+def test_failed_triangle_reupload_keeps_the_old_scene(pkg, hooks, oracle, monkeypatch):
     """ptmi_upload(TRIANGLES) allocates before it lets go of anything: when the board cannot hold a larger mesh the call fails and the
     context — every device of a multi-device one — keeps rendering the scene it had (never a freed buffer)."""
     b = pkg.scenes.golden_buffers("c2")
     view = cornell_view(pkg)
     big = np.tile(np.asarray(b["triangles"], np.float32).reshape(-1, 24), (24, 1))  # 2.2 MB of triangles
     for devices in (0, [0, 0]):
-        with pkg.Context(devices) as ctx:
+        with pkg.Context(devices, lib=hooks) as ctx:
             ctx.upload_scene(b)
             ctx.set_params(max_bounces=4)
             ctx.resize(96, 64)

@@ -26,9 +26,6 @@ using namespace ptmi;
 int ptmi_bvhdev_build_scene(void* stream, const float* d_tris, uint32_t n, const int32_t* h_meshes, int n_meshes, const float* h_xforms, int n_xforms, float* d_rows,
                             float* d_tris_out, int* depth_out, uint32_t* bad_tri, int sah, uint32_t* n_nodes_out);
 int ptmi_bvhdev_make_pairs(void* stream, const float* d_rows, uint32_t nn, float* d_pairs, int* d_leaf_table, uint32_t* n_multi);
-#ifdef PTMI_EXPERIMENTS
-int ptmi_diag_sort_pairs(void* stream, uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, uint32_t n);
-#endif
 
 namespace {
 
@@ -44,8 +41,10 @@ struct DBuf {
     cap = 0;
     if (bytes == 0) return hipSuccess;
     size_t ask = bytes;
-    if (const char* lim = getenv("PTMI_TEST_ALLOC_LIMIT"))  // tests: pretend the board is smaller — through a hipMalloc that really fails
+#ifdef PTMI_TEST_HOOKS  // the tests' own build of the library (_build.build_testhooks): pretend the board is smaller — through a hipMalloc that really fails
+    if (const char* lim = getenv("PTMI_TEST_ALLOC_LIMIT"))
       if (bytes > strtoull(lim, nullptr, 10)) ask = (size_t)1 << 60;
+#endif
     hipError_t e = hipMalloc(&p, ask);
     if (e == hipSuccess) cap = bytes;
     else {
@@ -138,10 +137,6 @@ struct Tuning {
   int path_budget_log2 = 29;   // PTMI_PATH_BUDGET_LOG2: paths per wavefront pass with frames_in_flight = auto
   int placement_tries = 4;     // PTMI_PLACEMENT_TRIES
   bool debug_placement = false;
-#ifdef PTMI_EXPERIMENTS
-  int bvh_kernel = 3;          // PTMI_BVH_KERNEL: 1 = first edition, 2 = second edition with one unified fetch, 3 = the shipped one
-  int diag_sort = 0;           // PTMI_DIAG_SORT
-#endif
 };
 
 struct ptmi_ctx {
@@ -186,9 +181,6 @@ struct ptmi_ctx {
   DBuf d_q0[2], d_q1[2], d_q2[2], d_tp[2], d_hm[2];  // slot-indexed live state and hit records, ping-pong
   DBuf d_uv, d_acc, d_pixsum, d_touched, d_ctl, d_totals, d_scratch, d_spill, d_heads;
   DBuf d_carry[2];  // Carry: the pools of saved traversal state, ping-pong like the queues
-#ifdef PTMI_EXPERIMENTS
-  DBuf d_diag[4];  // PTMI_DIAG_SORT: keys / slots, in / out
-#endif
   int ctl_cap = 0;
 
   // Render-ahead of ptmi_render_frame (see there): per-frame colours of frames [frame0, frame0 + count) sit in d_acc,
@@ -216,6 +208,11 @@ struct ptmi_ctx {
   PeerWorker* worker = nullptr;  // a peer's host thread (created on first use)
   int proc_rank = 0, proc_world = 1, proc_tile = 4032;  // (63 waves of pixels; not 4096: see dist.py — a rank's pixel count must not be a large power of two)
   bool use_rccl = false;
+  bool use_gather = false;        // the default collective of a multi-device context: every device's OWN tiles are copied into place on the root (1/N of the bytes, no arithmetic)
+  bool root_reads = false;        // (a peer's field) the root device can read this device's memory directly: peer access is on, or it is the same GPU
+  uint64_t gather_bytes = 0;      // bytes that crossed between GPUs in the last tile gather
+  int test_rccl_fail = 0;  // -DPTMI_TEST_HOOKS builds: PTMI_TEST_RCCL_FAIL=init|reduce|mid read at ptmi_create_multi — pretend ncclCommInitAll (1) / ncclGroupStart (2) failed, or
+                           // a call in the middle of the reduce's group after the first ncclReduce was enqueued (3); 0 in the product build
   std::vector<ncclComm_t> comms;  // one per local device, same order as {this, peers...}
   int reduce_mode = 0;            // ptmi_stats.reduce_mode: how the multi-device sum runs (0 single device, 1 RCCL, 2 peer copies + add, 3 the same as a FALLBACK)
   int peer_links = 0;             // directed device pairs (root <-> peer) with peer access enabled
@@ -755,10 +752,6 @@ void load_tuning(ptmi_ctx* c) {
   t.path_budget_log2 = std::max(16, std::min(31, env_int("PTMI_PATH_BUDGET_LOG2", t.path_budget_log2)));
   t.placement_tries = env_int("PTMI_PLACEMENT_TRIES", t.placement_tries);
   t.debug_placement = getenv("PTMI_DEBUG_PLACEMENT") != nullptr;
-#ifdef PTMI_EXPERIMENTS
-  t.bvh_kernel = env_int("PTMI_BVH_KERNEL", 3);
-  t.diag_sort = env_int("PTMI_DIAG_SORT", 0);
-#endif
   c->tun = t;
 }
 
@@ -773,27 +766,6 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
     else hipLaunchKernelGGL(k_prims<false>, dim3(pgrid), dim3(kBlock), 0, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), tot);
   }
   if (c->S.n_nodes <= 0) return PTMI_OK;
-#ifdef PTMI_EXPERIMENTS
-  // PTMI_DIAG_SORT=1|2|3 (an experiment, never the product path): hand k_bvh the queue's rays fully sorted by direction octant and origin cell, to
-  // measure what ANY ordering of the queue could buy the traversal (the sort itself runs outside the kernel's timing span and is not counted).
-  const uint32_t* diag_order = nullptr;
-  const uint32_t* diag_keys = nullptr;
-  const int diag = c->tun.diag_sort;
-  if (diag > 0 && !with_prims && !first_rc) {  // (not on step 0's queue: it does not store the origins the keys are made of)
-    for (int k = 0; k < 4; k++) HIP_TRY(c, c->d_diag[k].ensure((size_t)max_items * 4));
-    hipLaunchKernelGGL(k_diag_sort_keys, dim3(pgrid), dim3(kBlock), 0, c->stream, P, ctl, diag, c->d_diag[0].as<uint32_t>(), c->d_diag[2].as<uint32_t>(), max_items);
-    uint32_t nq = 0;
-    HIP_TRY(c, hipMemcpyAsync(&nq, &ctl->n_rays, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    nq = std::min(nq, max_items);
-    if (nq > 0) {
-      const int e = ptmi_diag_sort_pairs((void*)c->stream, c->d_diag[0].as<uint32_t>(), c->d_diag[1].as<uint32_t>(), c->d_diag[2].as<uint32_t>(), c->d_diag[3].as<uint32_t>(), nq);
-      if (e) return fail(c, PTMI_ERR_DEVICE, std::string("PTMI_DIAG_SORT: ") + hipGetErrorString((hipError_t)e));
-      diag_keys = c->d_diag[1].as<uint32_t>();
-      diag_order = c->d_diag[3].as<uint32_t>();
-    }
-  }
-#endif
   ScopedSpan sp(c, T_BVH);
   // Stack entries per lane: the first tun.lds_stack (10) in LDS, the rest (rarely reached) in a per-wave spill area.
   // 10 entries x 512 B + the candidate buffer (1 KB since round 4's three-group scan) = 6 KB per wave: 26 waves fit a CU's 160 KB, and the kernel's 66 VGPRs
@@ -807,12 +779,7 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
   // The abort of Q7 (hitRay.wgsl:106-109) needs sp to reach STACK_SIZE; sp never exceeds the number of inner nodes on a
   // root-to-leaf path.  PTMI_NOABORT=0 keeps the literal stack discipline for A/B runs.
   const bool noabort = c->bvh_depth < c->prm.stack_size && tun.noabort;
-#ifdef PTMI_EXPERIMENTS
-  const int edition = tun.bvh_kernel;
-#else
-  constexpr int edition = 3;
-#endif
-  int waves_per_cu = (int)std::min<size_t>(edition == 3 ? 28 : 20, (size_t)(160 * 1024) / (lds + 64));  // (editions 1 and 2 need 68-84 VGPRs)
+  int waves_per_cu = (int)std::min<size_t>(28, (size_t)(160 * 1024) / (lds + 64));
   if (tun.waves_per_cu > 0) waves_per_cu = tun.waves_per_cu;  // tuning aid; 0/unset = auto
   const uint32_t want = (max_items + 63) / 64;
   const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(want, (uint32_t)c->num_cus * (uint32_t)waves_per_cu));
@@ -826,26 +793,9 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
   // step 0's queue does not store the rays' common origin (k_generate): the kernel is handed cam_origin
   float4 cam = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   if (first_rc) cam = make_float4(first_rc->cam_o[0], first_rc->cam_o[1], first_rc->cam_o[2], 1.0f);
-#ifdef PTMI_EXPERIMENTS
-  // PTMI_BVH_KERNEL: 1 = the first edition of the traversal kernel (rounds 1/2), 2 = second edition with one unified fetch per iteration,
-  // 3 (default) = the shipped kernel — for A/B runs
-#define PTMI_LAUNCH_BVH_K1(KERNEL)                                                                                                                                    \
-  hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), n_teams, c->prm.stack_size, le, se, c->d_spill.as<int2>(), thr, \
-                     leaf_batch, tot, cam)
-#define PTMI_LAUNCH_BVH_K(KERNEL)                                                                                                                                     \
-  hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), n_teams, c->prm.stack_size, le, se, c->d_spill.as<int2>(), thr, \
-                     leaf_batch, tot, range_cap, cam, cy, diag_order, diag_keys)
-#define PTMI_LAUNCH_BVH(CNT, NA)                                       \
-  do {                                                                 \
-    if (edition == 1) PTMI_LAUNCH_BVH_K1((k_bvh<CNT, NA>));           \
-    else if (edition == 2) PTMI_LAUNCH_BVH_K((k_bvh2<CNT, NA, true>)); \
-    else PTMI_LAUNCH_BVH_K((k_bvh2<CNT, NA, false>));                  \
-  } while (0)
-#else
 #define PTMI_LAUNCH_BVH(CNT, NA)                                                                                                                                       \
-  hipLaunchKernelGGL((k_bvh2<CNT, NA, false>), dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), n_teams, c->prm.stack_size, le, se, \
+  hipLaunchKernelGGL((k_bvh2<CNT, NA>), dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), n_teams, c->prm.stack_size, le, se, \
                      c->d_spill.as<int2>(), thr, leaf_batch, tot, range_cap, cam, cy)
-#endif
   if (c->counters) {
     if (noabort) PTMI_LAUNCH_BVH(true, true);
     else PTMI_LAUNCH_BVH(true, false);
@@ -854,10 +804,6 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
     else PTMI_LAUNCH_BVH(false, false);
   }
 #undef PTMI_LAUNCH_BVH
-#ifdef PTMI_EXPERIMENTS
-#undef PTMI_LAUNCH_BVH_K
-#undef PTMI_LAUNCH_BVH_K1
-#endif
   HIP_TRY(c, hipGetLastError());
   return PTMI_OK;
 }
@@ -1130,6 +1076,7 @@ struct Rccl {
   void* lib = nullptr;
   decltype(&ncclCommInitAll) CommInitAll = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;
   decltype(&ncclReduce) Reduce = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -1155,6 +1102,7 @@ struct Rccl {
   }
     PTMI_RCCL_SYM(CommInitAll, ncclCommInitAll)
     PTMI_RCCL_SYM(CommDestroy, ncclCommDestroy)
+    PTMI_RCCL_SYM(CommAbort, ncclCommAbort)
     PTMI_RCCL_SYM(Reduce, ncclReduce)
     PTMI_RCCL_SYM(GroupStart, ncclGroupStart)
     PTMI_RCCL_SYM(GroupEnd, ncclGroupEnd)
@@ -1164,7 +1112,15 @@ struct Rccl {
   }
 };
 Rccl g_rccl;
-int g_test_rccl_fail = 0;  // PTMI_TEST_RCCL_FAIL=init|reduce (tests): pretend ncclCommInitAll / the reduce's group failed, so that the fall-back runs on any box
+// the fault a -DPTMI_TEST_HOOKS build was asked to simulate for this context; a constant 0 in the product build, so the branches and their messages fold away
+inline int rccl_fail_hook(const ptmi_ctx* c) {
+#ifdef PTMI_TEST_HOOKS
+  return c->test_rccl_fail;
+#else
+  (void)c;
+  return 0;
+#endif
+}
 std::once_flag g_rccl_once;  // two host threads may create multi-device contexts at the same time
 bool rccl_loaded() {
   std::call_once(g_rccl_once, [] { (void)g_rccl.load(); });
@@ -1204,6 +1160,16 @@ int on_all_devices(ptmi_ctx* c, F fn, bool parallel = false) {
   return rcs[0];
 }
 
+// One device's own tiles (ptmi_set_shard: pixels p with (p / tile) % world == rank) copied from its accumulation buffer into place in the root's gather buffer.  `src` may be
+// the peer's memory itself (peer access over xGMI: the kernel reads exactly the bytes it needs, 1/N of the buffer) or a staged copy of it.
+__global__ __launch_bounds__(kBlock) void k_gather_tiles(float4* __restrict__ dst, const float4* __restrict__ src, uint32_t n_local, int rank, int world, int tile) {
+  for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n_local; j += gridDim.x * kBlock) {
+    const uint32_t tl = j / (uint32_t)tile, within = j - tl * (uint32_t)tile;
+    const uint32_t pix = (tl * (uint32_t)world + (uint32_t)rank) * (uint32_t)tile + within;
+    dst[pix] = src[pix];
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_add_into(float4* __restrict__ dst, const float4* __restrict__ src, size_t n) {
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
     const float4 a = dst[i], b = src[i];
@@ -1235,9 +1201,9 @@ int gather_framebuffer(ptmi_ctx* c, float4** out) {
     // the first error inside it is noted after ncclGroupEnd.  An RCCL failure does not fail the read-back: the per-device buffers are
     // untouched partial sums, so the context switches to the peer-copy reduce below for good (reduce_mode 3) and sums them that way.
     std::string first_error;
-    ncclResult_t gs = g_test_rccl_fail == 2 ? ncclSystemError : g_rccl.GroupStart();
+    ncclResult_t gs = rccl_fail_hook(c) == 2 ? ncclSystemError : g_rccl.GroupStart();
     if (gs != ncclSuccess) {
-      first_error = std::string("ncclGroupStart: ") + (g_test_rccl_fail == 2 ? "simulated failure (PTMI_TEST_RCCL_FAIL=reduce)" : g_rccl.GetErrorString(gs));
+      first_error = std::string("ncclGroupStart: ") + (rccl_fail_hook(c) == 2 ? "simulated failure (PTMI_TEST_RCCL_FAIL=reduce)" : g_rccl.GetErrorString(gs));
     } else {
       for (size_t i = 0; i <= c->peers.size() && first_error.empty(); i++) {
         ptmi_ctx* q = i ? c->peers[i - 1] : c;
@@ -1248,9 +1214,18 @@ int gather_framebuffer(ptmi_ctx* c, float4** out) {
         }
         const ncclResult_t nr = g_rccl.Reduce(q->fb, i ? (void*)q->fb : (void*)g, n4 * 4, ncclFloat, ncclSum, 0, c->comms[i], q->stream);
         if (nr != ncclSuccess) first_error = std::string("ncclReduce (local device #") + std::to_string(i) + "): " + g_rccl.GetErrorString(nr);
+        else if (rccl_fail_hook(c) == 3) first_error = "simulated failure after the first ncclReduce was enqueued (PTMI_TEST_RCCL_FAIL=mid)";
       }
       const ncclResult_t ge = g_rccl.GroupEnd();
       if (first_error.empty() && ge != ncclSuccess) first_error = std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(ge);
+    }
+    if (!first_error.empty()) {
+      // A reduce that went out on some ranks only never completes: waiting for the streams first would hang instead of falling back.  So the
+      // communicators are aborted — that ends whatever they have in flight — and dropped before anybody synchronises (ncclCommDestroy on a
+      // communicator with an unfinished collective can block too: ptmi_destroy never sees these).
+      for (ncclComm_t cm : c->comms)
+        if (cm) (void)g_rccl.CommAbort(cm);
+      c->comms.clear();
     }
     hipError_t se = hipSuccess;
     for (size_t i = 0; i <= c->peers.size() && se == hipSuccess; i++) {  // whatever was enqueued has to drain before anybody reads or re-sums the buffers
@@ -1259,7 +1234,12 @@ int gather_framebuffer(ptmi_ctx* c, float4** out) {
       if (se == hipSuccess) se = hipStreamSynchronize(q->stream);
     }
     (void)hipSetDevice(c->device);
-    if (first_error.empty() && se != hipSuccess) first_error = std::string("after ncclReduce: ") + hipGetErrorString(se);
+    if (first_error.empty() && se != hipSuccess) {
+      first_error = std::string("after ncclReduce: ") + hipGetErrorString(se);
+      for (ncclComm_t cm : c->comms)
+        if (cm) (void)g_rccl.CommAbort(cm);
+      c->comms.clear();
+    }
     if (!first_error.empty()) {
       (void)hipGetLastError();
       c->use_rccl = false;
@@ -1267,7 +1247,36 @@ int gather_framebuffer(ptmi_ctx* c, float4** out) {
       c->reduce_info = "FALLBACK: hipMemcpyPeer + add (" + first_error + ")";
     }
   }
-  if (!c->use_rccl) {
+  if (!c->use_rccl && c->use_gather) {
+    // Tile gather (the default): every pixel belongs to exactly one device, so the image is the devices' own tiles put side by side — each peer's tiles are read
+    // straight out of its buffer by a kernel on the root (peer access over xGMI: 1/N of the buffer per peer, N - 1 reads in total instead of N - 1 full buffers,
+    // no arithmetic, no staging); a peer the root cannot read is staged through one hipMemcpyPeerAsync first.  Pixels no local device owns (another process's shard) stay zero.
+    HIP_TRY(c, hipMemsetAsync(g, 0, bytes, c->stream));
+    const uint32_t npix = (uint32_t)c->W * (uint32_t)c->H;
+    c->gather_bytes = 0;
+    for (size_t i = 0; i <= c->peers.size(); i++) {
+      ptmi_ctx* q = i ? c->peers[i - 1] : c;
+      const uint32_t n_local = count_local(npix, q->rank, q->world, q->tile);
+      if (n_local == 0) continue;
+      const float4* src = q->fb;
+      if (q->device != c->device && !q->root_reads) {
+        HIP_TRY(c, c->d_fb_stage.ensure(bytes));
+        HIP_TRY(c, hipMemcpyPeerAsync(c->d_fb_stage.p, c->device, q->fb, q->device, bytes, c->stream));
+        src = c->d_fb_stage.as<float4>();
+        c->gather_bytes += bytes;
+      } else if (q->device != c->device) {
+        c->gather_bytes += (uint64_t)n_local * 16;
+      }
+      const unsigned grid = (unsigned)std::min<size_t>(((size_t)n_local + kBlock - 1) / kBlock, (size_t)c->num_cus * 8);
+      hipLaunchKernelGGL(k_gather_tiles, dim3(grid), dim3(kBlock), 0, c->stream, g, src, n_local, q->rank, q->world, q->tile);
+      HIP_TRY(c, hipGetLastError());
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    char msg[200];
+    snprintf(msg, sizeof msg, "tile gather: every device's own tiles read into place by the root (%.1f MB between GPUs per read-back, of %.1f MB a full-buffer reduce would move)",
+             (double)c->gather_bytes / 1e6, (double)(c->peers.size() * bytes) / 1e6);
+    c->reduce_info = msg;
+  } else if (!c->use_rccl) {
     // shards that share this GPU (tests on a one-GPU box), or PTMI_MULTI_REDUCE=copy: peer copy + add kernel
     HIP_TRY(c, hipMemcpyAsync(g, c->fb, bytes, hipMemcpyDeviceToDevice, c->stream));
     const unsigned grid = (unsigned)std::min<size_t>((n4 + kBlock - 1) / kBlock, (size_t)c->num_cus * 8);
@@ -1413,9 +1422,12 @@ int ptmi_create_multi(ptmi_ctx** out, const int* device_ids, int n_devices) {
   // The reduce: RCCL whenever every shard has a GPU of its own (a communicator cannot hold one GPU twice); shards that
   // share a GPU are summed by a kernel.  PTMI_MULTI_REDUCE=copy forces the peer-copy path, =rccl forces RCCL even for a
   // single device (a one-rank communicator: exercises the library on a one-GPU box).
+  // PTMI_MULTI_REDUCE: gather (default: the devices' own tiles copied into place, 1/N of the bytes), rccl (ncclReduce of the full buffers — north_star's wording —; needs
+  // distinct GPUs; forces RCCL even for a single device: a one-rank communicator, which exercises the library on a one-GPU box), copy (peer copies + add kernel)
   const char* mode = getenv("PTMI_MULTI_REDUCE");
   const bool force_rccl = mode && !strcmp(mode, "rccl"), force_copy = mode && !strcmp(mode, "copy");
-  c->use_rccl = !force_copy && distinct && (n_devices > 1 || force_rccl);
+  c->use_rccl = force_rccl && distinct;
+  c->use_gather = !force_rccl && !force_copy;
   if (force_rccl && !distinct) {
     ptmi_destroy(c);
     return fail(nullptr, PTMI_ERR_UNSUPPORTED, "PTMI_MULTI_REDUCE=rccl needs distinct device ids (an RCCL communicator cannot hold a GPU twice)");
@@ -1429,16 +1441,23 @@ int ptmi_create_multi(ptmi_ctx** out, const int* device_ids, int n_devices) {
         int can = 0;
         if (hipSetDevice(from) != hipSuccess || hipDeviceCanAccessPeer(&can, from, to) != hipSuccess || !can) continue;
         const hipError_t pe = hipDeviceEnablePeerAccess(to, 0);
-        if (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) c->peer_links++;
+        if (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) {
+          c->peer_links++;
+          if (dir == 0) q->root_reads = true;  // (enabled on the root for the peer's memory)
+        }
         (void)hipGetLastError();
       }
     }
     (void)hipSetDevice(c->device);
   }
-  const char* tf = getenv("PTMI_TEST_RCCL_FAIL");
-  g_test_rccl_fail = !tf ? 0 : !strcmp(tf, "init") ? 1 : !strcmp(tf, "reduce") ? 2 : 0;
-  c->reduce_mode = n_devices > 1 || force_rccl ? 2 : 0;
-  c->reduce_info = n_devices > 1 ? (distinct ? "hipMemcpyPeer + add (PTMI_MULTI_REDUCE=copy)" : "add kernel (shards share a GPU)") : "single device";
+#ifdef PTMI_TEST_HOOKS
+  if (const char* tf = getenv("PTMI_TEST_RCCL_FAIL")) c->test_rccl_fail = !strcmp(tf, "init") ? 1 : !strcmp(tf, "reduce") ? 2 : !strcmp(tf, "mid") ? 3 : 0;
+#endif
+  for (ptmi_ctx* q : c->peers)
+    if (q->device == c->device) q->root_reads = true;
+  c->reduce_mode = n_devices > 1 || force_rccl ? (c->use_gather ? 4 : 2) : 0;
+  c->reduce_info = n_devices > 1 ? (c->use_gather ? "tile gather: every device's own tiles read into place by the root" : distinct ? "hipMemcpyPeer + add (PTMI_MULTI_REDUCE=copy)" : "add kernel (shards share a GPU)")
+                                 : "single device";
   if (c->use_rccl) {
     // The RCCL path has to be able to fail without taking the context with it: if the library cannot be loaded or the communicators cannot be
     // made, the reduce falls back to peer copies + an add kernel (bit-identical: every pixel is non-zero in one buffer) and says so.
@@ -1447,9 +1466,9 @@ int ptmi_create_multi(ptmi_ctx** out, const int* device_ids, int n_devices) {
       why = "cannot load librccl (" + g_rccl.why + "); set PTMI_RCCL_LIB";
     } else {
       c->comms.assign((size_t)n_devices, nullptr);
-      const ncclResult_t nr = g_test_rccl_fail == 1 ? ncclSystemError : g_rccl.CommInitAll(c->comms.data(), n_devices, device_ids);
+      const ncclResult_t nr = rccl_fail_hook(c) == 1 ? ncclSystemError : g_rccl.CommInitAll(c->comms.data(), n_devices, device_ids);
       if (nr != ncclSuccess) {
-        why = std::string("ncclCommInitAll: ") + (g_test_rccl_fail == 1 ? "simulated failure (PTMI_TEST_RCCL_FAIL=init)" : g_rccl.GetErrorString(nr));
+        why = std::string("ncclCommInitAll: ") + (rccl_fail_hook(c) == 1 ? "simulated failure (PTMI_TEST_RCCL_FAIL=init)" : g_rccl.GetErrorString(nr));
         c->comms.clear();
         (void)hipGetLastError();
         (void)hipSetDevice(c->device);
@@ -1493,9 +1512,6 @@ void ptmi_destroy(ptmi_ctx* c) {
                   &c->d_q2[1], &c->d_tp[0], &c->d_tp[1], &c->d_hm[0], &c->d_hm[1], &c->d_uv, &c->d_acc, &c->d_pixsum, &c->d_touched, &c->d_ctl, &c->d_totals,
                   &c->d_scratch, &c->d_spill, &c->d_heads, &c->d_fb_gather, &c->d_fb_stage, &c->d_bvh_rows, &c->d_carry[0], &c->d_carry[1]})
     b->release();
-#ifdef PTMI_EXPERIMENTS
-  for (DBuf& b : c->d_diag) b.release();
-#endif
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c->worker;
   delete c;
@@ -1523,11 +1539,12 @@ int ptmi_set_params(ptmi_ctx* c, const ptmi_params* p) {
 
 int ptmi_reload_tuning(ptmi_ctx* c) {
   if (!c) return PTMI_ERR_INVALID_ARG;
-  load_tuning(c);
-  c->ahead.valid = false;
-  for (ptmi_ctx* q : c->peers) {
+  for (size_t i = 0; i <= c->peers.size(); i++) {
+    ptmi_ctx* q = i ? c->peers[i - 1] : c;
+    const int slots_before = q->tun.bvh_carry_slots;
     load_tuning(q);
     q->ahead.valid = false;
+    if (q->tun.bvh_carry_slots > slots_before) q->path_cap = 0;  // the queues were sized with the old carry prefix (ensure_paths): allocate them again
   }
   return PTMI_OK;
 }

@@ -948,21 +948,3 @@ int ptmi_bvhdev_make_pairs(void* stream_, const float* d_rows, uint32_t nn, floa
   }
 }
 
-#ifdef PTMI_EXPERIMENTS
-// PTMI_DIAG_SORT (experiment): device-wide radix sort of (key, slot) pairs; scratch allocated per call
-int ptmi_diag_sort_pairs(void* stream_, uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, uint32_t n) {
-  hipStream_t stream = (hipStream_t)stream_;
-  try {
-    Dev d;
-    size_t tb = 0;
-    TRY(rocprim::radix_sort_pairs(nullptr, tb, keys_in, keys_out, vals_in, vals_out, n, 0, 32, stream));
-    char* temp;
-    TRY(d.alloc(&temp, tb));
-    TRY(rocprim::radix_sort_pairs(temp, tb, keys_in, keys_out, vals_in, vals_out, n, 0, 32, stream));
-    TRY(hipStreamSynchronize(stream));
-    return (int)hipSuccess;
-  } catch (...) {
-    return (int)hipErrorOutOfMemory;
-  }
-}
-#endif  // PTMI_EXPERIMENTS

@@ -124,11 +124,8 @@ DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 // candidate against the compiler's expansion over all 2^32 arguments on the device (tests/test_math.py::test_exhaustive_*).
 //   rcp:  inside |x| in [2^-100, 2^100] v_div_scale and v_div_fixup are identities and v_div_fmas is an fma, so the expansion
 //         with numerator 1 is y1 = fma(fma(-x, y0, 1), y0, y0); q1 = fma(fma(-x, y1, 1), y1, y1); q = fma(fma(-x, q1, 1), y1, q1).
-//         PTMI_RCP_STEPS picks how much of it is evaluated (the exhaustive test says what is enough); outside the range, the division.
+//         Exhaustively (ptmi_selftest 0): the first step, y1, already has the bits of 1.0f / x for every x in the range; outside it, the division.
 //   sqrt: inside x in [2^-90, 2^120] the scaling, un-scaling and the zero/inf pass-through drop out of the expansion.
-#ifndef PTMI_RCP_STEPS
-#define PTMI_RCP_STEPS 1  // exhaustively: one Newton step on v_rcp_f32 already gives the bits of 1.0f / x for every x in the range
-#endif
 // The out-of-range path: a call where registers are plentiful and code size matters (k_shade: inlining it cost configs[1] 4 %),
 // inline inside k_bvh, whose triangle test pays for the registers saved around a call (configs[3]: 4 %).
 __device__ __attribute__((noinline)) float rcp_ieee_slow(float x) {
@@ -141,11 +138,7 @@ __device__ __attribute__((noinline)) float sqrt_ieee_slow(float x) {
 }
 DEV float rcp_core(float x) {  // valid for |x| in [2^-100, 2^100]
   const float y0 = __builtin_amdgcn_rcpf(x);
-  const float y1 = __builtin_fmaf(__builtin_fmaf(-x, y0, 1.0f), y0, y0);
-  if (PTMI_RCP_STEPS == 1) return y1;
-  const float q1 = __builtin_fmaf(__builtin_fmaf(-x, y1, 1.0f), y1, y1);
-  if (PTMI_RCP_STEPS == 2) return q1;
-  return __builtin_fmaf(__builtin_fmaf(-x, q1, 1.0f), y1, q1);
+  return __builtin_fmaf(__builtin_fmaf(-x, y0, 1.0f), y0, y0);
 }
 DEV bool rcp_in_range(uint32_t bits) { return ((bits & 0x7fffffffu) - (27u << 23)) < (200u << 23); }  // biased exponent in [27, 227)
 DEV float rcp_exact(float x) {
@@ -173,22 +166,8 @@ DEV f3 rcp3_exact_il(f3 a) {
   if (max(ex, max(ey, ez)) >= (200u << 23)) r = mk3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z);
   return r;
 }
-#ifndef PTMI_SQRT_VARIANT
-#define PTMI_SQRT_VARIANT 2  // 0 = round 3's (v_sqrt_f32 + the residual test of its two neighbours: 12 instructions, ~38 issue cycles), 1 / 2 = sqrt_cand A / C below
-#endif
 DEV float sqrt_cand(float x, int which);
-DEV float sqrt_exact_r3(float x);
-DEV float sqrt_exact(float x) { return PTMI_SQRT_VARIANT == 0 ? sqrt_exact_r3(x) : sqrt_cand(x, PTMI_SQRT_VARIANT == 1 ? 0 : 2); }
-DEV float sqrt_exact_r3(float x) {
-  // the compiler's sequence without its scaling: s = v_sqrt(x) is within 1 ulp; its neighbours are tried against the exact residuals
-  const float s = __builtin_amdgcn_sqrtf(x);
-  const float dn = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
-  const float rd = __builtin_fmaf(-dn, s, x), ru = __builtin_fmaf(-up, s, x);
-  float r = (rd <= 0.0f) ? dn : s;
-  r = (ru > 0.0f) ? up : r;
-  if ((__float_as_uint(x) - (37u << 23)) >= (210u << 23)) r = sqrt_ieee_slow(x);  // x < 2^-90 (incl. 0, negative: sign bit set) or >= 2^120 (incl. inf, NaN)
-  return r;
-}
+DEV float sqrt_exact(float x) { return sqrt_cand(x, 2); }  // candidate C below (round 3's v_sqrt_f32 + residual test of both neighbours was 12 instructions)
 // Shorter sequences with the IEEE bits (round 4; ptmi_selftest 5..7 run each over all 2^32 arguments on the device): one Markstein correction
 // s + (x - s*s) * h of v_sqrt_f32's result with h ~ 1/(2s) from v_rsq_f32 (A: 0 mismatches) or from v_rcp_f32 (B: 105 mismatches — not used), and the two-step
 // scheme from v_rsq_f32 alone (C: 0 mismatches; one transcendental, 7 instructions, ~20 issue cycles — the one in use).  Same guarded range as round 3's.
@@ -603,36 +582,6 @@ DEV void obj_ray_uniform(const DevScene& S, f3 o, f3 d, ObjRay& r) {
   r.d = mk3(mat_mul_cols(c0, c1, c2, c3, d, 0.0f));
 }
 
-#ifdef PTMI_EXPERIMENTS  // the first edition of the traversal (rounds 1/2), kept for A/B builds only (_build.build_variant)
-// shaders/common.wgsl:191-222 (the accept/reject part; normal, p and material are reconstructed
-// from (index, u, v) by resolve_hit once the closest hit is final)
-template <bool COUNT>
-DEV void hit_triangle(const DevScene& S, int k, f3 o, f3 d, ObjRay& orr, Closest& c, Counters& cn) {
-  const float4* pt = S.pretri + 4 * (size_t)k;
-  float4 t0 = pt[0], t1 = pt[1], t2 = pt[2], t3 = pt[3];
-  int mesh = __float_as_int(t0.w);
-  if (mesh != orr.mesh) obj_ray_for(S, mesh, __float_as_int(t2.w), o, d, orr);
-  if (COUNT) cn.tri_tests++;
-  f3 A = mk3(t0), AB = mk3(t1), AC = mk3(t2), N = mk3(t3);
-  float det = -dot3(orr.d, N);
-  if (ptm_abs(det) < S.tmin) return;
-  f3 ao = orr.o - A;
-  f3 dao = cross3(ao, orr.d);
-  float invDet = rcp_exact_il(det);
-  float dst = dot3(ao, N) * invDet;
-  float u = dot3(AC, dao) * invDet;
-  float v = -dot3(AB, dao) * invDet;
-  float w = 1.0f - u - v;
-  if (dst < S.tmin || dst > c.t || u < S.tmin || v < S.tmin || w < S.tmin) return;
-  c.t = dst;
-  c.u = u;
-  c.v = v;
-  c.prim = (K_TRI << 28) | (uint32_t)k;
-  c.mat = __float_as_int(t1.w);
-  if (COUNT) cn.mat_fetches++;
-}
-
-#endif  // PTMI_EXPERIMENTS
 
 // t-interval of a ray against one box, the closest-independent part of hit_aabb (common.wgsl:246-253):
 // ts = max(tmin, max3(tsmaller)), tb = min3(tbigger); the box passes iff min(closest, tb) > ts.
@@ -645,182 +594,6 @@ DEV void slab(float4 lo, float4 hi, f3 o, f3 inv, float tmin, float& ts, float& 
   tb = ptm_min(bx, ptm_min(by, bz));
 }
 
-#ifdef PTMI_EXPERIMENTS  // first edition, continued: its stack, its per-lane state and its phases
-template <bool COUNT>
-DEV void visit_leaf(const DevScene& S, uint32_t ref, f3 o, f3 d, ObjRay& orr, Closest& c, Counters& cn) {
-  if (ref & REF_MULTI) {  // hitRay.wgsl:59-68 with prim_count != 1 (external BVHs)
-    int2 lc = S.leaf_table[ref & REF_IDX];
-    for (int j = 0; j < lc.y; j++) hit_triangle<COUNT>(S, lc.x + j, o, d, orr, c, cn);
-  } else {
-    hit_triangle<COUNT>(S, (int)(ref & REF_IDX), o, d, orr, c, cn);
-  }
-}
-
-// shaders/hitRay.wgsl:42-110 — stack traversal, front-to-back by the split axis, with the reference's
-// exact visit order, box-test outcomes and stack depth (Q7).  What differs is only WHERE the bytes come
-// from: an inner node's record carries both children's boxes, the near child is tested at once (the
-// reference tests it in its very next iteration with the same closest_so_far), and the far child is
-// pushed together with its closest-independent interval start `ts` and two flag bits, so that when the
-// reference would pop and re-test it against the then-current closest_so_far, the outcome
-//     min(closest, tb) > ts   ==   isnan(closest) ? B : (A && closest > ts)
-// (A = tb > ts || isnan(tb), B = tb > ts; min drops NaNs, ptmi_math.h) is evaluated from the stack
-// entry alone.
-//
-// The traversal is a per-lane state machine so that a wave can interleave rays (lane refill):
-//   cur     = pair index of an inner node whose box has passed, T_POP (take the next stack entry) or T_DONE
-//   pending = ref of a leaf whose box has passed and whose triangles are still to be tested, 0 = none
-// The stack of a lane: entries 0 .. lds_entries-1 live in LDS (word w of entry e at lds[(2e+w)*64], `lds` being the
-// lane's column), deeper ones in a per-wave spill area in global memory (entry e at spill[(e-lds_entries)*64], `spill`
-// pointing at the lane's column).  Keeping at most 14 entries per lane in LDS is what lets a CU hold 20 waves (5 per
-// SIMD) on deep trees; with NOABORT hardly any ray ever has more entries than that.
-struct LaneStack {
-  int* lds;
-  int2* spill;
-  int lds_entries;
-};
-DEV void stack_write(const LaneStack& k, int e, uint32_t w0, float w1) {
-  if (e < k.lds_entries) {
-    k.lds[(2 * e) * 64] = (int)w0;
-    k.lds[(2 * e + 1) * 64] = __float_as_int(w1);
-  } else {
-    k.spill[(e - k.lds_entries) * 64] = make_int2((int)w0, __float_as_int(w1));
-  }
-}
-DEV void stack_read(const LaneStack& k, int e, uint32_t& w0, float& w1) {
-  if (e < k.lds_entries) {
-    w0 = (uint32_t)k.lds[(2 * e) * 64];
-    w1 = __int_as_float(k.lds[(2 * e + 1) * 64]);
-  } else {
-    const int2 v = k.spill[(e - k.lds_entries) * 64];
-    w0 = (uint32_t)v.x;
-    w1 = __int_as_float(v.y);
-  }
-}
-//
-// NOABORT: when the tree is shallower than STACK_SIZE the abort of Q7 cannot happen, so the stack DEPTH no longer
-// matters, only its content.  A far child whose box the ray misses outright (A = B = 0: it fails the re-test whatever
-// closest_so_far has become) is then not pushed at all — its visit is counted on the spot.  ~45 % of all stack
-// entries on the measured scenes are of that kind.
-constexpr uint32_t T_DONE = 0xffffffffu, T_POP = 0xfffffffeu;
-
-struct Trav {
-  f3 o, d, inv;
-  ObjRay orr;
-  Closest c;
-  uint32_t cur, pending;
-  int sp;
-  uint32_t negmask;  // bit a = (d[a] < 0)
-};
-
-// Triangle test on an already fetched pretri record (same arithmetic as hit_triangle).
-template <bool COUNT>
-DEV void tri_record_test(const DevScene& S, int k, float4 t0, float4 t1, float4 t2, float4 t3, Trav& t, Counters& cn) {
-  int mesh = __float_as_int(t0.w);
-  if (mesh != t.orr.mesh) obj_ray_for(S, mesh, __float_as_int(t2.w), t.o, t.d, t.orr);
-  if (COUNT) cn.tri_tests++;
-  f3 A = mk3(t0), AB = mk3(t1), AC = mk3(t2), N = mk3(t3);
-  float det = -dot3(t.orr.d, N);
-  if (ptm_abs(det) < S.tmin) return;
-  f3 ao = t.orr.o - A;
-  f3 dao = cross3(ao, t.orr.d);
-  float invDet = rcp_exact_il(det);
-  float dst = dot3(ao, N) * invDet;
-  float u = dot3(AC, dao) * invDet;
-  float v = -dot3(AB, dao) * invDet;
-  float w = 1.0f - u - v;
-  if (dst < S.tmin || dst > t.c.t || u < S.tmin || v < S.tmin || w < S.tmin) return;
-  t.c.t = dst;
-  t.c.u = u;
-  t.c.v = v;
-  t.c.prim = (K_TRI << 28) | (uint32_t)k;
-  t.c.mat = __float_as_int(t1.w);
-  if (COUNT) cn.mat_fetches++;
-}
-
-// Flat traversal: one 64-byte record fetch per lane per phase — the pair record of an inner node or the pretri
-// record of a pending triangle, both 4 x float4.  Failing stack entries are popped right away (LDS only), so that a
-// lane always has a record to fetch next.  Visit order and outcomes are those of trav_step/visit_leaf.
-// The two phases are separate functions so that the caller can run the (rarer) triangle phase only when enough
-// lanes wait for it: every phase costs its full instruction count however few lanes take part.
-DEV void trav_pop_until_pass(const LaneStack& stk, Trav& t, Counters& cn, bool count) {
-  while (t.cur == T_POP && t.pending == 0u) {
-    if (t.sp == 0) {
-      t.cur = T_DONE;
-      break;
-    }
-    t.sp--;
-    uint32_t e;
-    float ts;
-    stack_read(stk, t.sp, e, ts);
-    if (count) cn.node_visits++;
-    const float ct = t.c.t;
-    // isnan(ct) ? B : (A && ct > ts), written without a branch: ct > ts is false for a NaN ct
-    const bool pass = (((e & REF_A) != 0u) & (ct > ts)) | ((ct != ct) & ((e & REF_B) != 0u));
-    if (pass) {
-      if (e & REF_LEAF) t.pending = e;
-      else t.cur = e & REF_IDX;
-    }
-  }
-}
-
-// lanes with a pending leaf: test its triangle(s), then pop
-template <bool COUNT>
-DEV void trav_leaf_phase(const DevScene& S, const LaneStack& stk, Trav& t, Counters& cn) {
-  if (t.pending & REF_MULTI) {  // prim_count != 1 (external BVHs): rare
-    visit_leaf<COUNT>(S, t.pending, t.o, t.d, t.orr, t.c, cn);
-  } else {
-    const int k = (int)(t.pending & REF_IDX);
-    const float4* rec = S.pretri + 4 * (size_t)k;
-    const float4 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3v = rec[3];
-    tri_record_test<COUNT>(S, k, f0, f1, f2, f3v, t, cn);
-  }
-  t.pending = 0u;
-  trav_pop_until_pass(stk, t, cn, COUNT);
-}
-
-// lanes at an inner node (cur < T_POP, no pending leaf): one reference visit of its near child, far child pushed
-template <bool COUNT, bool NOABORT>
-DEV void trav_inner_phase(const DevScene& S, int stack_size, const LaneStack& stk, Trav& t, Counters& cn) {
-  const float4* rec = S.pairs + 4 * (size_t)t.cur;
-  const float4 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3v = rec[3];
-  float tsL, tbL, tsR, tbR;
-  slab(f0, f1, t.o, t.inv, S.tmin, tsL, tbL);
-  slab(f2, f3v, t.o, t.inv, S.tmin, tsR, tbR);
-  const int axis = __float_as_int(f2.w);
-  const bool neg = ((t.negmask >> axis) & 1u) != 0u;
-  const uint32_t refL = __float_as_uint(f0.w), refR = __float_as_uint(f1.w);
-  const uint32_t nearRef = neg ? refR : refL;
-  uint32_t farRef = neg ? refL : refR;
-  const float tsN = neg ? tsR : tsL, tbN = neg ? tbR : tbL;
-  const float tsF = neg ? tsL : tsR, tbF = neg ? tbL : tbR;
-  const bool fB = tbF > tsF;
-  const bool fA = fB || (tbF != tbF);
-  farRef |= (fA ? REF_A : 0u) | (fB ? REF_B : 0u);
-  if (NOABORT) {
-    if (fA) {  // (B implies A)
-      stack_write(stk, t.sp, farRef, tsF);
-      t.sp++;
-    } else if (COUNT) {
-      cn.node_visits++;  // the pop + failed re-test the reference performs later
-    }
-  } else {
-    stack_write(stk, t.sp, farRef, tsF);
-    t.sp++;
-    if (t.sp >= stack_size) {  // Q7
-      t.cur = T_DONE;
-      return;
-    }
-  }
-  if (COUNT) cn.node_visits++;
-  t.cur = T_POP;
-  if (ptm_min(t.c.t, tbN) > tsN) {
-    if (nearRef & REF_LEAF) t.pending = nearRef;
-    else t.cur = nearRef;
-  }
-  trav_pop_until_pass(stk, t, cn, COUNT);
-}
-
-#endif  // PTMI_EXPERIMENTS
 
 // ---- second edition of the traversal state machine (k_bvh2) -----------------------------------------------------------
 // Same visits, same outcomes, same counters as trav_inner_phase / trav_leaf_phase / trav_pop_until_pass; what changed is how

@@ -88,12 +88,8 @@ __global__ __launch_bounds__(kBlock) void k_generate(DevScene S, RenderConst rc,
 
 // 96 VGPRs (5 waves/SIMD, no spills) measured 27 % faster than the compiler's default 106 VGPRs / 4 waves: the kernel
 // is latency bound; 6 and 8 waves/SIMD spill and lose again.
-#ifndef PTMI_SHADE_ATTR
 #define PTMI_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(5, 8)))
-#endif
-#ifndef PTMI_BVH_ATTR
 #define PTMI_BVH_ATTR __attribute__((amdgpu_waves_per_eu(5, 8)))
-#endif
 
 // Rank of this lane's entry within its material bin for the current chunk (counting sort, pass 1).
 // Must be called from wave-uniform control flow; lanes without an entry pass bin = -1.
@@ -147,140 +143,6 @@ constexpr int kLeafBatch = 16;
 constexpr uint32_t kBvhRange = 512;  // slots a wave claims per global atomic (less when the queue is short); round 3: 256..1024 equal within noise, 2048 +1 %, 8192 +6 % (the last ranges are a tail)
 
 
-#ifdef PTMI_EXPERIMENTS  // first edition of k_bvh (rounds 1/2; PTMI_BVH_KERNEL=1 in an experiments build)
-// hitScene, part 2 (hitRay.wgsl:42-110): BVH traversal by persistent, barrier-free waves.
-// One block = one wave, so LDS (the first lds_entries stack entries of every lane, 512 B each, plus a candidate buffer)
-// and the 96-VGPR budget are what limit how many waves a CU holds (20).  A wave claims ranges of queue SLOTS (one global
-// atomic per <= 2048 slots, on its team's counter), scans the HITMAT_BVH flags 64 slots at a time into its candidate
-// buffer, and hands candidates to idle lanes: each lane runs the traversal state machine on one ray, and whenever
-// kRefillThreshold lanes have finished they are refilled, so short rays never leave lanes idle behind a long one and
-// tails exist only at kernel end.  (A team's waves share an XCD; dealing consecutive ranges to one team in runs of 8 or
-// 64 so that neighbouring rays share that XCD's L2 measured +-0: after the first bounce rays are incoherent.)
-// Flat traversal: one 64-byte record fetch (pair or triangle) per lane per iteration.
-//   NOABORT = the tree is shallower than STACK_SIZE (see ptmi_device.h): far children that miss outright are not pushed.
-template <bool COUNT, bool NOABORT>
-__global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh(DevScene S, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads, uint32_t n_teams, int stack_size,
-                                                                                       int lds_entries, int spill_entries, int2* __restrict__ spill,
-                                                                                       int refill_threshold, int leaf_batch,
-                                                                                       unsigned long long* __restrict__ totals, float4 cam) {
-  extern __shared__ int lds_stack[];
-  const int lane = lane_id();
-  LaneStack stk;
-  stk.lds = lds_stack + lane;
-  stk.spill = spill + (size_t)blockIdx.x * (size_t)spill_entries * 64 + lane;
-  stk.lds_entries = lds_entries;
-  uint32_t* cand = reinterpret_cast<uint32_t*>(lds_stack + lds_entries * 2 * 64);  // [128] candidate slots
-  const uint32_t n = ctl->n_rays;
-  // short queues (the Russian-roulette tail) are cut into smaller ranges so that they still spread over all waves
-  const uint32_t range = min(kBvhRange, max(64u, ((n / (2u * gridDim.x)) + 63u) & ~63u));
-  const uint32_t team = blockIdx.x % n_teams;
-  Counters cn = {0, 0, 0, 0, 0};
-  uint32_t rb = 0, re = 0;   // this wave's claimed range of slots still to be scanned (wave-uniform)
-  uint32_t ncand = 0;        // candidates waiting in `cand` (wave-uniform)
-  bool exhausted = (n == 0);
-  bool has = false;
-  uint32_t myslot = 0;
-  Trav t;
-  t.cur = T_DONE;
-  t.pending = 0;
-  t.sp = 0;
-  t.negmask = 0;
-  t.o = t.d = t.inv = mk3(0, 0, 0);
-  t.orr.mesh = -1;
-  t.orr.o = t.orr.d = mk3(0, 0, 0);
-  t.c.t = 0.0f, t.c.u = t.c.v = 0.0f, t.c.prim = K_NONE, t.c.mat = 0;
-  const uint32_t root = __float_as_uint(S.root_lo.w);
-  for (;;) {
-    // retire finished rays (stores only: nothing here waits on memory)
-    if (has && t.cur == T_DONE && t.pending == 0u) {
-      if ((t.c.prim >> 28) == K_TRI) {  // a triangle beat what part 1 had found; otherwise the record stands as it is
-        P.hin.tp[myslot] = make_float2(t.c.t, __uint_as_float(t.c.prim));
-        P.uv[myslot] = make_float2(t.c.u, t.c.v);
-        P.hin.mat[myslot] = (uint32_t)t.c.mat;
-      }
-      has = false;
-    }
-    uint64_t hm = __ballot(has);
-    int nact = __popcll(hm);
-    if ((64 - nact) >= (nact == 0 ? 1 : refill_threshold)) {
-      const uint32_t want = (uint32_t)(64 - nact);
-      // top up the candidate buffer: scan 64 slots at a time until it holds enough or the queue is exhausted
-      while (ncand < want && !(exhausted && rb == re)) {
-        if (rb == re) {  // claim the next range of slots
-          // range r belongs to team r % n_teams; the waves of a team (every n_teams-th wave) share that team's counter:
-          // one counter for everybody means tens of thousands of same-address atomics per launch at ~11 ns each
-          uint32_t i = 0;
-          if (lane == 0) i = atomicAdd(&heads[team * kHeadStride], 1u);
-          i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
-          const uint64_t nb64 = ((uint64_t)team + (uint64_t)n_teams * i) * range;
-          if (nb64 >= (uint64_t)n) {
-            exhausted = true;
-            continue;
-          }
-          const uint32_t nb = (uint32_t)nb64;
-          rb = nb;
-          re = min(nb + range, n);
-        }
-        const uint32_t slot = rb + (uint32_t)lane;
-        const bool flagged = slot < re && (P.hin.mat[slot] & HITMAT_BVH) != 0u;
-        const uint64_t fm = __ballot(flagged);
-        if (flagged) cand[ncand + lanes_below(fm)] = slot;
-        ncand += (uint32_t)__popcll(fm);
-        rb = min(rb + 64u, re);
-      }
-      if (ncand) {
-        const uint64_t idle = ~hm;
-        const uint32_t k = lanes_below(idle);
-        const uint32_t take = min(ncand, want);
-        if (!has && k < take) {
-          myslot = cand[ncand - 1u - k];
-          float4 r0 = cam, r1 = P.in.q1[myslot];
-          if (cam.w == 0.0f) r0 = P.in.q0[myslot];  // (step 0's queue does not store the common origin)
-          float2 h = P.hin.tp[myslot];
-          const uint32_t hmat = P.hin.mat[myslot] & HITMAT_WORD;
-          t.o = mk3(r0);
-          t.d = mk3(r1);
-          t.inv = rcp3_exact_il(t.d);
-          t.negmask = (t.d.x < 0 ? 1u : 0u) | (t.d.y < 0 ? 2u : 0u) | (t.d.z < 0 ? 4u : 0u);
-          t.c.t = h.x, t.c.u = 0.0f, t.c.v = 0.0f, t.c.prim = __float_as_uint(h.y);
-          t.c.mat = (hmat != HITMAT_MISS) ? (int)hmat : 0;
-          t.orr.mesh = -1;
-          t.sp = 0;
-          if (root & REF_LEAF) {
-            t.pending = root;
-            t.cur = T_POP;
-          } else {
-            t.pending = 0;
-            t.cur = root & REF_IDX;
-          }
-          has = true;
-        }
-        ncand -= take;
-        hm = __ballot(has);
-        nact = __popcll(hm);
-      }
-    }
-    if (nact == 0) break;  // nothing in flight, nothing buffered, queue exhausted
-    const bool more = ncand > 0 || !(exhausted && rb == re);
-    const int min_working = more ? (64 - refill_threshold + 1) : 1;
-    int working;
-    {
-      do {
-        // triangle phase only when a batch of lanes waits for it, or nothing else can run
-        const uint64_t pm = __ballot(has && t.pending != 0u);
-        const uint64_t im = __ballot(has && t.pending == 0u && t.cur < T_POP);
-        if (pm && (__popcll(pm) >= leaf_batch || im == 0ull)) {
-          if (has && t.pending != 0u) trav_leaf_phase<COUNT>(S, stk, t, cn);
-        }
-        if (has && t.pending == 0u && t.cur < T_POP) trav_inner_phase<COUNT, NOABORT>(S, stack_size, stk, t, cn);
-        working = __popcll(__ballot(has && !(t.cur == T_DONE && t.pending == 0u)));
-      } while (working >= min_working);
-    }
-  }
-  if (COUNT) reduce_counters(cn, totals, true);
-}
-
-#endif  // PTMI_EXPERIMENTS
 
 // k_bvh, second edition (round 3).  Same scheduling (persistent single-wave blocks, team counters, flag scan, ballot refill),
 // same per-ray visit order, outcomes and counters; three changes to where the instructions and the round trips go:
@@ -309,17 +171,11 @@ __device__ unsigned long long g_tail_tally[3 * kBvhTallies];
 #define BT(k, dep, lanes) ((void)0)
 #endif
 constexpr int kScanGroups = 3, kCandSlots = 64 * (kScanGroups + 1);  // a pass adds at most 64 x kScanGroups candidates to fewer than 64
-template <bool COUNT, bool NOABORT, bool UNIFIED>
+template <bool COUNT, bool NOABORT>
 DEV void bvh2_body(const DevScene& S, const Paths& P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads, uint32_t n_teams, int stack_size, int lds_entries, int spill_entries,
                    int2* __restrict__ spill, int refill_threshold, int leaf_batch, unsigned long long* __restrict__ totals, uint32_t range_cap, float4 cam, const Carry& cy,
                    int* lds_stack, uint32_t wave_id, uint32_t n_waves  // (stand where blockIdx.x / gridDim.x would: a wave works on its own)
-#ifdef PTMI_EXPERIMENTS
-                   , const uint32_t* __restrict__ diag_order, const uint32_t* __restrict__ diag_keys
-#endif
 ) {
-#ifndef PTMI_EXPERIMENTS
-  static_assert(!UNIFIED, "the unified-fetch loop is an experiment (measured and dropped, DESIGN.md / profiles/NOTES_r03.md): build with -DPTMI_EXPERIMENTS");
-#endif
   const int lane = lane_id();
   LaneStack2 stk;
   stk.lds = (lds_v2i_t*)lds_stack + lane;
@@ -386,18 +242,6 @@ DEV void bvh2_body(const DevScene& S, const Paths& P, StepCtl* __restrict__ ctl,
           rb = nb;
           re = min(nb + range, n);
         }
-#ifdef PTMI_EXPERIMENTS
-        if (diag_order) {  // PTMI_DIAG_SORT: the queue's BVH rays in an explicit, fully sorted order instead of slot order
-          uint32_t slot = rb + (uint32_t)lane;
-          const bool flagged = slot < re && diag_keys[slot] != 0xffffffffu;
-          if (flagged) slot = diag_order[slot];
-          const uint64_t fm = __ballot(flagged);
-          if (flagged) cand[ncand + lanes_below(fm)] = slot;
-          ncand += (uint32_t)__popcll(fm);
-          rb = min(rb + 64u, re);
-          continue;
-        }
-#endif
         // kScanGroups x 64 flag words per pass, the loads in flight together: where few slots are flagged (configs[1]: one in twelve — the mesh is
         // small in the room) a refill is a chain of such round trips, and with the tree in LDS they were a quarter of the wave's time
         uint32_t word[kScanGroups];
@@ -455,44 +299,6 @@ DEV void bvh2_body(const DevScene& S, const Paths& P, StepCtl* __restrict__ ctl,
     const bool more = ncand > 0 || !(exhausted && rb == re);
     const int min_working = more ? (64 - refill_threshold + 1) : 1;
     int working;
-#ifdef PTMI_EXPERIMENTS
-    if (UNIFIED) {
-    float4 f0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), f1 = f0, f2 = f0, f3v = f0;
-    bool fetched = false;  // f0..f3v hold the pretri record of this lane's pending triangle
-    do {
-      const bool isinner = node < N_INNER_LIMIT;
-      const bool isleaf = (int)node < 0;
-      const bool simple = isleaf && !(node & REF_MULTI);
-      if (isinner || (simple && !fetched)) {
-        const float4* rec = simple ? S.pretri + 4 * (size_t)(node & REF_IDX) : S.pairs + 4 * (size_t)node;
-        f0 = rec[0], f1 = rec[1], f2 = rec[2], f3v = rec[3];
-        fetched = simple;
-      }
-      const uint64_t pm = __ballot(isleaf), im = __ballot(isinner);
-      // triangles only when a batch of lanes waits for them, or nothing else can run
-      const bool run_leaf = pm != 0ull && (__popcll(pm) >= leaf_batch || im == 0ull);
-      uint32_t next = node;
-      if (isinner) next = inner_step2<COUNT, NOABORT>(f0, f1, f2, f3v, o, inv, S.tmin, negmask, ct, stack_size, stk, sp, cn);
-      if (run_leaf && isleaf) {
-        if (simple) {
-          tri_test2<COUNT>(S, (int)(node & REF_IDX), f0, f1, f2, f3v, o, d, orr, ct, hit, cn);
-        } else {  // prim_count != 1 (external / SAH trees): rare
-          const int2 lc = S.leaf_table[node & REF_IDX];
-          for (int j = 0; j < lc.y; j++) {
-            const float4* rec = S.pretri + 4 * (size_t)(lc.x + j);
-            const float4 g0 = rec[0], g1 = rec[1], g2 = rec[2], g3 = rec[3];
-            tri_test2<COUNT>(S, lc.x + j, g0, g1, g2, g3, o, d, orr, ct, hit, cn);
-          }
-        }
-        fetched = false;
-        next = N_POP;
-      }
-      if (next == N_POP) next = pop_until_pass2(stk, sp, ct, cn, COUNT);
-      node = next;
-      working = __popcll(__ballot(node != N_DONE));
-    } while (working >= min_working);
-    } else
-#endif
     {
     // Two phases per iteration, each with its own fetch: the triangle records are the coldest data of the
     // scene, and a wave waits for the slowest lane of a fetch — mixing them into every pair fetch (UNIFIED) made every wait a slow one
@@ -574,51 +380,18 @@ DEV void bvh2_body(const DevScene& S, const Paths& P, StepCtl* __restrict__ ctl,
   if (COUNT) reduce_counters(cn, totals, true);
 }
 
-template <bool COUNT, bool NOABORT, bool UNIFIED>
+template <bool COUNT, bool NOABORT>
 __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads, uint32_t n_teams, int stack_size,
                                                            int lds_entries, int spill_entries, int2* __restrict__ spill, int refill_threshold, int leaf_batch,
                                                            unsigned long long* __restrict__ totals, uint32_t range_cap, float4 cam,  // cam.w != 0: step 0's queue — every ray starts at cam.xyz
                                                            Carry cy
-#ifdef PTMI_EXPERIMENTS
-                                                           , const uint32_t* __restrict__ diag_order, const uint32_t* __restrict__ diag_keys
-#endif
 ) {
   extern __shared__ int lds_stack[];
-  bvh2_body<COUNT, NOABORT, UNIFIED>(S, P, ctl, heads, n_teams, stack_size, lds_entries, spill_entries, spill, refill_threshold, leaf_batch, totals, range_cap, cam, cy, lds_stack,
+  bvh2_body<COUNT, NOABORT>(S, P, ctl, heads, n_teams, stack_size, lds_entries, spill_entries, spill, refill_threshold, leaf_batch, totals, range_cap, cam, cy, lds_stack,
                                      blockIdx.x, gridDim.x
-#ifdef PTMI_EXPERIMENTS
-                                            , diag_order, diag_keys
-#endif
   );
 }
 
-#ifdef PTMI_EXPERIMENTS
-// PTMI_DIAG_SORT: sort key of every slot of a queue — 0xffffffff for slots k_bvh has nothing to do for; else direction octant and a 27-bit
-// Morton code of the origin in [-1.5, 1.5]^3 (mode 1: octant major, mode 2: origin major, mode 3: origin only).  Experiment only.
-DEV uint32_t diag_spread3(uint32_t v) {  // 9 bits -> every third bit
-  v &= 0x1ffu;
-  v = (v | (v << 16)) & 0x030000ffu;
-  v = (v | (v << 8)) & 0x0300f00fu;
-  v = (v | (v << 4)) & 0x030c30c3u;
-  v = (v | (v << 2)) & 0x09249249u;
-  return v;
-}
-__global__ __launch_bounds__(kBlock) void k_diag_sort_keys(Paths P, const StepCtl* __restrict__ ctl, int mode, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t n_alloc) {
-  const uint32_t n = min(ctl->n_rays, n_alloc);
-  for (uint32_t slot = blockIdx.x * kBlock + threadIdx.x; slot < n; slot += gridDim.x * kBlock) {
-    uint32_t key = 0xffffffffu;
-    if (P.hin.mat[slot] & HITMAT_BVH) {
-      const float4 a0 = P.in.q0[slot], a1 = P.in.q1[slot];
-      const uint32_t oct = (a1.x < 0 ? 1u : 0u) | (a1.y < 0 ? 2u : 0u) | (a1.z < 0 ? 4u : 0u);
-      auto cell = [](float x) { return (uint32_t)fminf(fmaxf((x + 1.5f) * (512.0f / 3.0f), 0.0f), 511.0f); };
-      const uint32_t mort = diag_spread3(cell(a0.x)) | (diag_spread3(cell(a0.y)) << 1) | (diag_spread3(cell(a0.z)) << 2);  // 27 bits
-      key = mode == 1 ? ((oct << 27) | mort) : mode == 2 ? ((mort << 3) | oct) : mort;
-    }
-    keys[slot] = key;
-    vals[slot] = slot;
-  }
-}
-#endif  // PTMI_EXPERIMENTS
 
 // What a surviving path carries into the next step's queue.
 struct NewState {
@@ -822,27 +595,13 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
   }
 }
 
-#ifndef PTMI_SCHUNK
-#define PTMI_SCHUNK 512
-#endif
-#ifndef PTMI_SHADE_WAVE
-#define PTMI_SHADE_WAVE 1  // A/B: 0 = every variant runs the block version (three barriers per chunk)
-#endif
-#ifndef PTMI_SHADE_SORT_WAVE
-#define PTMI_SHADE_SORT_WAVE 0  // A/B: 1 = the sorted variants run wave by wave with per-class bins instead of the block version's LDS counting sort and its three
-                                // barriers per 512-slot chunk (round 4: built, bit-exact, 2.5 % SLOWER on configs[4] — 61.3 vs 59.8 ms per 64 spp, profiles/r04_sort_wave_ab.txt:
-                                // the barriers are not what that kernel waits for; the gathers by slot number and the bin bookkeeping cost more than they save)
-#endif
-#ifndef PTMI_REGION_DIV
-#define PTMI_REGION_DIV 16  // A/B: a block's share of the queue is claimed in this many regions (x4: every wave claims its own)
-#endif
-#ifndef PTMI_MISS_SHORTCUT
-#define PTMI_MISS_SHORTCUT 1
-#endif
+// (Measured and settled, so no longer build options: the sorted variants wave by wave with per-class bins instead of the block version's LDS counting sort
+// — bit-exact, 2.5 % slower on configs[4], profiles/r04_sort_wave_ab.txt —; every variant through the block version; other region / chunk sizes.)
+constexpr uint32_t kRegionDiv = 16;  // a block's share of the queue is claimed in this many regions (x4: every wave claims its own)
 constexpr int kTailLimitFirst = 2 << 20, kTailLimitLater = 1 << 20;  // k_tail takes a queue over when it is at most this long (slots): at step 0 (a lone 1080p frame fits) / later (round 4: 512 Ki -> 1 Mi since its tree walk waits for 24 lanes — 8-frame batches of configs[1] +5 %, 64-frame ones and configs[2] unchanged: profiles/r04_tail_limit_ab.txt)
 constexpr int kTailRefill = 16;  // k_tail: idle lanes before a wave takes new paths
-constexpr bool kMissShortcut = PTMI_MISS_SHORTCUT != 0;  // A/B: settle definite misses in k_shade's flush phase
-constexpr int kSChunk = PTMI_SCHUNK;  // slots a k_shade block sorts, shades and compacts at a time
+constexpr bool kMissShortcut = true;  // definite misses are settled in k_shade's flush phase
+constexpr int kSChunk = 512;  // slots a k_shade block sorts, shades and compacts at a time
 
 // ray_color's loop body for one step, 512 slots at a time per block:
 //   1  (SORT) LDS counting sort of the chunk by the shade bin in each slot's material word (ballot ranks), so that
@@ -853,12 +612,12 @@ constexpr int kSChunk = PTMI_SCHUNK;  // slots a k_shade block sorts, shades and
 //      record go to the block's current OUTPUT REGION of the next queue, coalesced.  A block claims a region with one
 //      global atomic (16 or so per launch), fills it across chunks — an entry that does not fit any more continues in
 //      the next region — and marks what is left at the end as holes.
-template <bool IS, bool SORT, bool COUNT, bool MULTI>
+template <bool IS, bool COUNT, bool MULTI>
 DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads, unsigned long long* __restrict__ totals,
                     int first, uint32_t resv) {
   reset_heads(heads);
   __shared__ float4 s_q0[kSChunk], s_q1[kSChunk], s_q2[kSChunk];
-  __shared__ uint16_t s_sorted[SORT ? kSChunk : 1];
+  __shared__ uint16_t s_sorted[kSChunk];
   __shared__ uint32_t s_cnt[NUM_BINS + 2];
   __shared__ uint32_t s_nout, s_next;
   const QuadL L = load_light(S);
@@ -868,7 +627,7 @@ DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, St
   if (n <= resv && n_carried == 0u) n = 0u;
   // region size: a block handles about n / gridDim slots per launch; 1/16 of that per claim keeps both the
   // number of atomics and the holes left at the end (at most one region per block) small
-  const uint32_t region = max((uint32_t)kSChunk, ((n / gridDim.x / (uint32_t)PTMI_REGION_DIV) + 511u) & ~511u);
+  const uint32_t region = max((uint32_t)kSChunk, ((n / gridDim.x / kRegionDiv) + 511u) & ~511u);
   const uint32_t wregion = region / (kBlock / 64);  // every wave fills output regions of its own (>= 128 slots): no barrier, no serial section in the flush phase
   uint32_t w_cur = 0, w_rend = 0;                   // this wave's current output region [w_cur, w_rend) of the next queue (wave-uniform)
   // The waves' FIRST regions come from one claim per block, made by whichever wave needs a region first; the others pick their quarter
@@ -898,19 +657,19 @@ DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, St
   };
   for (uint32_t base = blockIdx.x * (uint32_t)kSChunk; base < n; base += gridDim.x * (uint32_t)kSChunk) {
     const uint32_t m = min((uint32_t)kSChunk, n - base);
-    if (SORT && threadIdx.x < NUM_BINS) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < NUM_BINS) s_cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
       s_nout = 0;
       s_next = 0;
     }
     __syncthreads();
-    if (SORT) {
+    {
       // ---- 1: sort ----
       uint32_t keys[kSChunk / kBlock];
       uint32_t words[kSChunk / kBlock];  // the thread's material words, asked for together (with a branch around each load they went one after the other: round 4's reading of the ISA)
-#pragma unroll
+  #pragma unroll
       for (int r = 0; r < kSChunk / kBlock; r++) words[r] = P.hin.mat[base + min((uint32_t)r * kBlock + threadIdx.x, m - 1u)];
-#pragma unroll
+  #pragma unroll
       for (int r = 0; r < kSChunk / kBlock; r++) {
         const uint32_t j = (uint32_t)r * kBlock + threadIdx.x;
         int bin = -1;
@@ -926,17 +685,17 @@ DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, St
       uint32_t nvalid = 0;
       {
         uint32_t off[NUM_BINS];
-#pragma unroll
+  #pragma unroll
         for (int b = 0; b < NUM_BINS; b++) {
           off[b] = nvalid;
           nvalid += s_cnt[b];
         }
-#pragma unroll
+  #pragma unroll
         for (int r = 0; r < kSChunk / kBlock; r++) {
           if (keys[r] != 0xffffffffu) {
             const uint32_t b = keys[r] & 7u;
             uint32_t o = off[0];
-#pragma unroll
+  #pragma unroll
             for (int k = 1; k < NUM_BINS; k++) o = (b == (uint32_t)k) ? off[k] : o;
             s_sorted[o + (keys[r] >> 3)] = (uint16_t)((uint32_t)r * kBlock + threadIdx.x);
           }
@@ -958,39 +717,11 @@ DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, St
         NewState ns;
         ns.o = ns.d = ns.T = mk3(0, 0, 0);
         ns.bounce = 0, ns.rng = 0, ns.pid = 0;
-#ifdef PTMI_NS_ZERO
-      ns.o = ns.d = ns.T = mk3(0, 0, 0);
-      ns.bounce = 0, ns.rng = 0, ns.pid = 0;
-#endif
         if (k < nvalid) {
           const SlotState st = load_slot(P, base + s_sorted[k], first != 0, rc);
           const TriFetch tf = tri_fetch(S, P.uv, st.slot, __float_as_uint(st.tp.y));  // (issued ahead of the material's loads, consumed after them)
           survive = shade_one<IS, MULTI>(S, rc, P, st, tf, L, ns);
         }
-        stage(survive, ns);
-      }
-    } else {
-      // ---- 2 (unsorted): slots in queue order; a hole's loads are simply ignored ----
-#pragma unroll 1
-      for (uint32_t j0 = (threadIdx.x & ~63u); j0 < m; j0 += kBlock) {
-        const uint32_t j = j0 + lane;
-        bool survive = false, valid = false;
-        NewState ns;
-        ns.o = ns.d = ns.T = mk3(0, 0, 0);
-        ns.bounce = 0, ns.rng = 0, ns.pid = 0;
-#ifdef PTMI_NS_ZERO
-      ns.o = ns.d = ns.T = mk3(0, 0, 0);
-      ns.bounce = 0, ns.rng = 0, ns.pid = 0;
-#endif
-        if (j < m && !dead_slot(base + j, n_carried, resv)) {
-          const SlotState st = load_slot(P, base + j, first != 0, rc);
-          valid = __float_as_uint(st.q1.w) != PID_HOLE;
-          if (valid) {
-            const TriFetch tf = tri_fetch(S, P.uv, st.slot, __float_as_uint(st.tp.y));  // (issued ahead of the material's loads, consumed after them)
-            survive = shade_one<IS, MULTI>(S, rc, P, st, tf, L, ns);
-          }
-        }
-        my_valid += (uint32_t)__popcll(__ballot(valid));
         stage(survive, ns);
       }
     }
@@ -1107,22 +838,13 @@ DEV void shade_body(const DevScene& S, const RenderConst& rc, const Paths& P, St
 // the same 64-slot groups of the block's chunks as in shade_body, stages its survivors in an LDS ring of its own (128 entries) and runs a
 // flush pass — hitScene part 1 for 64 new rays, all lanes busy — whenever 64 are waiting; what is left goes out in one last, partial pass.
 // (shade_body's three barriers per chunk had every wave wait for the block's slowest three times per 128 slots of its own work.)
-//
-// SORT (scenes with several material classes, round 4): the same wave-by-wave loop with BINS in front of it instead of the block version's counting sort and
-// its three barriers per chunk.  A wave reads the material words of its 64-slot group, and the slots whose class is Lambertian, mirror or glass go into a
-// ring of slot numbers per class (3 x 128 x 4 bytes per wave); a class is shaded whenever 64 of its slots wait — one class per pass, all lanes busy, state
-// gathered by slot number from neighbouring groups — and what is left goes out in partial passes at the end.  Misses ride along with the Lambertian class,
-// the rare classes (isotropic media, unknown material types) are shaded at once, with the group.  ONE call site of shade_one for all of it (a work loop that picks a full bin,
-// else the next group): the kernel is 4.7 k instructions as it is.
-template <bool IS, bool SORT, bool COUNT, bool MULTI>
+template <bool IS, bool COUNT, bool MULTI>
 DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads,
                          unsigned long long* __restrict__ totals, int first, uint32_t resv) {
   reset_heads(heads);
-  constexpr uint32_t kRing = 128, kWaves = kBlock / 64, kBins = 3;
+  constexpr uint32_t kRing = 128, kWaves = kBlock / 64;
   static_assert((size_t)kWaves * kRing == (size_t)kSChunk, "the rings take the LDS the block version's staging arrays take");
-  static_assert(BIN_LAMBERTIAN == 0 && BIN_MIRROR == 1 && BIN_GLASS == 2, "the binned classes are material types 0..2");
   __shared__ float4 s_q0[kWaves * kRing], s_q1[kWaves * kRing], s_q2[kWaves * kRing];
-  __shared__ uint32_t s_bin[SORT ? kWaves * kBins * kRing : 1];
   constexpr uint32_t kR0Empty = 0xffffffffu, kR0Busy = 0xfffffffeu, kR0Full = 0xfffffffdu;
   __shared__ uint32_t s_region0;  // the waves' first regions: one claim per block (see shade_body)
   if (threadIdx.x == 0) s_region0 = kR0Empty;
@@ -1139,7 +861,7 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
   const uint32_t n_carried = resv ? min(ctl->n_carried, resv) : 0u;  // (Carry: slots [n_carried, resv) of this queue hold nothing)
   uint32_t n = ctl->n_rays;
   if (n <= resv && n_carried == 0u) n = 0u;
-  const uint32_t region = max((uint32_t)kSChunk, ((n / gridDim.x / (uint32_t)PTMI_REGION_DIV) + 511u) & ~511u);
+  const uint32_t region = max((uint32_t)kSChunk, ((n / gridDim.x / kRegionDiv) + 511u) & ~511u);
   const uint32_t wregion = region / kWaves;
   uint32_t w_cur = 0, w_rend = 0;  // this wave's current output region of the next queue (wave-uniform)
   uint32_t head = 0, cnt = 0;      // the ring: `cnt` survivors wait from entry `head` on (wave-uniform)
@@ -1156,12 +878,7 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
       const float4 a0 = r0[q], a1 = r1[q];
       TT(TT_RING_READ, a0.x + a1.x);
       rng = __float_as_uint(a0.w);
-#ifdef PTMI_PROBE_NO_FLUSH  // timing probe (wrong images): what does k_shade cost without hitScene part 1?
-      tp = make_float2(1.0f + a1.x * 0.0f, __uint_as_float((K_QUAD << 28) | 1u));
-      hm = 0u;
-#else
       prims_for_ray<COUNT>(S, mk3(a0), mk3(a1), rng, tp, hm, cn);
-#endif
       TT(TT_FLUSH_PRIMS, tp.x + __uint_as_float(hm));
       if (kMissShortcut && !MULTI && hm == HITMAT_MISS) {  // traceRay.wgsl:12-16 (see shade_body)
         LT(LT_MISS_SHORTCUT);
@@ -1266,14 +983,7 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
     cnt += (uint32_t)__popcll(mk);
     TT(TT_STAGE, 0.0f);
   };
-  // ... a flush pass whenever 64 wait
-  auto shade_slots = [&](bool active, uint32_t slot) {
-    SlotState st;
-    if (active) st = load_slot(P, slot, first != 0, rc);
-    shade_group(active, st);
-    if (cnt >= 64u) flush_pass(64u);
-  };
-  if (!SORT) {
+  {
     // The wave's groups — slots base + j0 .. + 63 of the block's chunks — one after the other, the NEXT group's state requested before the flush pass of
     // the current one: the loads travel while the wave tests quads (round 4: a wave spent 11 % of its cycles waiting for exactly these loads)
     uint32_t base = blockIdx.x * (uint32_t)kSChunk, j0 = wv * 64u;
@@ -1305,55 +1015,6 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
       cur = nxt;
       cur_act = nxt_act;
     }
-  } else {
-    uint32_t* const bins = s_bin + wv * kBins * kRing;
-    uint32_t bcnt = 0, bhead = 0;  // the three bins' counts and ring heads, a byte each (wave-uniform)
-    uint32_t base = blockIdx.x * (uint32_t)kSChunk, j0 = wv * 64u;  // the next group: slots base + j0 .. + 63
-    bool final = false;
-#pragma unroll 1
-    for (;;) {
-      bool active = false;
-      uint32_t slot = 0;
-      int b = -1;  // a class with a full pass waiting (any waiting slot once the groups are used up)
-#pragma unroll
-      for (int k = (int)kBins - 1; k >= 0; k--)
-        if (((bcnt >> (8 * k)) & 0xffu) >= (final ? 1u : 64u)) b = k;
-      if (b >= 0) {
-        const uint32_t c = (bcnt >> (8 * b)) & 0xffu, h = (bhead >> (8 * b)) & 0xffu, take = min(c, 64u);
-        active = (uint32_t)lane < take;
-        if (active) slot = bins[(uint32_t)b * kRing + ((h + (uint32_t)lane) & (kRing - 1u))];
-        bcnt -= take << (8 * b);
-        bhead = (bhead & ~(0xffu << (8 * b))) | (((h + take) & (kRing - 1u)) << (8 * b));
-      } else if (!final) {
-        while (base < n && j0 >= min((uint32_t)kSChunk, n - base)) {  // this wave's groups of the block's current chunk are used up
-          base += gridDim.x * (uint32_t)kSChunk;
-          j0 = wv * 64u;
-        }
-        if (base >= n) {
-          final = true;
-          continue;
-        }
-        slot = base + j0 + (uint32_t)lane;
-        j0 += kBlock;
-        int bin = 7;  // 7 = nothing here (hole, dead slot, beyond the chunk)
-        if (slot - base < min((uint32_t)kSChunk, n - base) && !dead_slot(slot, n_carried, resv)) bin = (int)((P.hin.mat[slot] >> HITMAT_BIN_SHIFT) & 7u);
-        if (bin == BIN_MISS) bin = BIN_LAMBERTIAN;  // a miss is a few instructions at the head of shade_one: it rides along with the most common class instead of costing a pass (and a memory round trip) of its own
-#pragma unroll
-        for (int k = 0; k < (int)kBins; k++) {
-          const uint64_t bm = __ballot(bin == k);
-          if (bm) {
-            const uint32_t c = (bcnt >> (8 * k)) & 0xffu, h = (bhead >> (8 * k)) & 0xffu;
-            if (bin == k) bins[(uint32_t)k * kRing + ((h + c + lanes_below(bm)) & (kRing - 1u))] = slot;
-            bcnt += (uint32_t)__popcll(bm) << (8 * k);
-          }
-        }
-        active = bin >= (int)kBins && bin < 7;  // the rare classes (isotropic media, unknown material types): with the group
-        if (__ballot(active) == 0ull) continue;
-      } else {
-        break;
-      }
-      shade_slots(active, slot);
-    }
   }
   if (cnt) flush_pass(cnt);
   if (MULTI) my_missed = 0;  // (no path ends in the flush phase then)
@@ -1383,17 +1044,14 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
 template <bool IS, bool SORT, bool COUNT, bool MULTI>
 __global__ __launch_bounds__(kBlock) PTMI_SHADE_ATTR void k_shade(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads,
                                                                   unsigned long long* __restrict__ totals, int first, uint32_t resv) {
-  if constexpr (PTMI_SHADE_WAVE == 0 || (SORT && PTMI_SHADE_SORT_WAVE == 0)) shade_body<IS, SORT, COUNT, MULTI>(S, rc, P, ctl, heads, totals, first, resv);
-  else shade_body_wave<IS, SORT, COUNT, MULTI>(S, rc, P, ctl, heads, totals, first, resv);
+  if constexpr (SORT) shade_body<IS, COUNT, MULTI>(S, rc, P, ctl, heads, totals, first, resv);  // several material classes: block by block, sorted
+  else shade_body_wave<IS, COUNT, MULTI>(S, rc, P, ctl, heads, totals, first, resv);            // one class: wave by wave
 }
 template <bool SORT, bool COUNT>
-#ifndef PTMI_SHADE6_WAVES
-#define PTMI_SHADE6_WAVES 6
-#endif
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PTMI_SHADE6_WAVES, 8))) void k_shade6(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_shade6(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl,
                                                                                                 uint32_t* __restrict__ heads, unsigned long long* __restrict__ totals, int first, uint32_t resv) {
-  if constexpr (PTMI_SHADE_WAVE == 0 || (SORT && PTMI_SHADE_SORT_WAVE == 0)) shade_body<false, SORT, COUNT, false>(S, rc, P, ctl, heads, totals, first, resv);
-  else shade_body_wave<false, SORT, COUNT, false>(S, rc, P, ctl, heads, totals, first, resv);
+  if constexpr (SORT) shade_body<false, COUNT, false>(S, rc, P, ctl, heads, totals, first, resv);
+  else shade_body_wave<false, COUNT, false>(S, rc, P, ctl, heads, totals, first, resv);
 }
 
 // k_tail — a SHORT queue traced to the end in one launch: every lane takes a path and runs ray_color's loop for it (hitScene part 2 on
@@ -1403,10 +1061,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PTMI_SHA
 // default MAX_BOUNCES = 100.  Launched in front of every step's k_bvh; declines (all blocks return at once) unless 0 < n_rays <= limit;
 // when it has run, the block that finishes last zeroes the queue length, so the step's k_bvh / k_shade and every later step find nothing.
 // Same per-ray arithmetic and visit order as the wavefront kernels (the same device functions), same counters and tallies.
-#ifndef PTMI_TAIL_TRAV_BATCH
-#define PTMI_TAIL_TRAV_BATCH 24
-#endif
-constexpr int kTailTravBatch = PTMI_TAIL_TRAV_BATCH;
+constexpr int kTailTravBatch = 24;  // (12 / 32 / 40 lanes measured: profiles/r04_tail_trav_batch.txt)
 template <bool IS, bool COUNT, bool MULTI, bool NOABORT>
 DEV void tail_body(const DevScene& S, const RenderConst& rc, const Paths& P, StepCtl* __restrict__ ctl, unsigned long long* __restrict__ totals, int first, uint32_t limit,
                    int stack_size, int lds_entries, int spill_entries, int2* __restrict__ spill, const Carry& cy) {

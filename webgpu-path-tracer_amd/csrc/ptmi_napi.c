@@ -48,6 +48,7 @@ FN(ptmi_build_bvh)
 FN(ptmi_build_bvh_sah)
 FN(ptmi_build_bvh_device)
 FN(ptmi_build_scene_bvh)
+FN(ptmi_build_scene_bvh_sah)
 FN(ptmi_obj_parse)
 FN(ptmi_free)
 FN(ptmi_device_count)
@@ -84,7 +85,7 @@ static int load_lib(char* err, size_t errlen) {
   LOAD(ptmi_version) LOAD(ptmi_last_error) LOAD(ptmi_create) LOAD(ptmi_create_multi) LOAD(ptmi_prepare) LOAD(ptmi_destroy) LOAD(ptmi_default_params) LOAD(ptmi_set_params)
   LOAD(ptmi_get_params) LOAD(ptmi_upload) LOAD(ptmi_resize) LOAD(ptmi_clear_framebuffer) LOAD(ptmi_set_shard) LOAD(ptmi_render_frame)
   LOAD(ptmi_render) LOAD(ptmi_synchronize) LOAD(ptmi_read_framebuffer) LOAD(ptmi_write_framebuffer) LOAD(ptmi_resolve_rgba8)
-  LOAD(ptmi_set_counters) LOAD(ptmi_set_timing) LOAD(ptmi_get_stats) LOAD(ptmi_reset_stats) LOAD(ptmi_build_bvh) LOAD(ptmi_build_bvh_sah) LOAD(ptmi_build_bvh_device) LOAD(ptmi_build_scene_bvh)
+  LOAD(ptmi_set_counters) LOAD(ptmi_set_timing) LOAD(ptmi_get_stats) LOAD(ptmi_reset_stats) LOAD(ptmi_build_bvh) LOAD(ptmi_build_bvh_sah) LOAD(ptmi_build_bvh_device) LOAD(ptmi_build_scene_bvh) LOAD(ptmi_build_scene_bvh_sah)
   LOAD(ptmi_obj_parse) LOAD(ptmi_free) LOAD(ptmi_device_count) LOAD(ptmi_reduce_info)
   return 0;
 }
@@ -418,6 +419,17 @@ static napi_value js_build_scene_bvh(napi_env env, napi_callback_info info) {
   return NULL;
 }
 
+/* the same with the reference's other builder, BVH.generate_bvh_heirarchy_SAH (lib/BVH/bvhNode.js:108-283), which its renderer never calls: an opt-in */
+static napi_value js_build_scene_bvh_sah(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (get_args(env, info, 1, a)) return NULL;
+  ptmi_ctx* c = ctx_of(env, a[0]);
+  if (!c) return NULL;
+  int st = p_ptmi_build_scene_bvh_sah(c);
+  if (st) return throw_status(env, c, st, "ptmi_build_scene_bvh_sah");
+  return NULL;
+}
+
 static napi_value js_read_fb(napi_env env, napi_callback_info info) {
   napi_value a[2];
   if (get_args(env, info, 2, a)) return NULL;
@@ -660,7 +672,7 @@ static napi_value init(napi_env env, napi_value exports) {
   } fns[] = {
       {"version", js_version}, {"create", js_create}, {"destroy", js_destroy}, {"defaultParams", js_default_params}, {"setParams", js_set_params},
       {"upload", js_upload}, {"resize", js_resize}, {"clear", js_clear}, {"setShard", js_set_shard}, {"renderFrame", js_render_frame},
-      {"render", js_render}, {"synchronize", js_synchronize}, {"prepare", js_prepare}, {"buildSceneBVH", js_build_scene_bvh}, {"readFramebuffer", js_read_fb}, {"writeFramebuffer", js_write_fb},
+      {"render", js_render}, {"synchronize", js_synchronize}, {"prepare", js_prepare}, {"buildSceneBVH", js_build_scene_bvh}, {"buildSceneBVHSAH", js_build_scene_bvh_sah}, {"readFramebuffer", js_read_fb}, {"writeFramebuffer", js_write_fb},
       {"resolveRGBA8", js_resolve}, {"setCounters", js_set_counters}, {"setTiming", js_set_timing}, {"stats", js_stats},
       {"resetStats", js_reset_stats}, {"buildBVH", js_build_bvh}, {"buildBVHSAH", js_build_bvh_sah}, {"buildBVHDevice", js_build_bvh_device}, {"parseObj", js_parse_obj},
       {"deviceCount", js_device_count}, {"reduceInfo", js_reduce_info},

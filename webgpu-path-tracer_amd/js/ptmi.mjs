@@ -32,6 +32,7 @@ export class Ptmi {
   render(view16, firstFrame, nFrames) { this.native.render(this.h, view16, firstFrame, nFrames); }
   synchronize() { this.native.synchronize(this.h); }
   prepare() { this.native.prepare(this.h); }
+  buildSceneBVHSAH() { this.native.buildSceneBVHSAH(this.h); }   // the same with the reference's never-called SAH builder (lib/BVH/bvhNode.js:108-283): opt-in
   buildSceneBVH() { this.native.buildSceneBVH(this.h); }   // Scene.create_bvh() (lib/scene.js:253-259) on the GPU, over the uploaded unordered triangles
   readFramebuffer(out = new Float32Array(this.width * this.height * 4)) { return this.native.readFramebuffer(this.h, out); }
   writeFramebuffer(src) { this.native.writeFramebuffer(this.h, src); }

@@ -53,22 +53,27 @@ class PtmiError(RuntimeError):
 
 
 _lib = None
+_libs = {}
 
 
 def lib_path():
     return _build.LIB
 
 
-def load_library(build=False):
-    """dlopen libptmi.so (optionally building it first).  Raises if it is not there."""
+def load_library(build=False, path=None):
+    """dlopen libptmi.so (optionally building it first).  Raises if it is not there.  `path`: another build of the library next to the default
+    one (the tests' fault-injection build, _build.build_testhooks) — pass the result to Context(..., lib=...)."""
     global _lib
-    if _lib is not None:
+    if path is None and _lib is not None:
         return _lib
+    if path is not None and path in _libs:
+        return _libs[path]
     if build:
         _build.build_lib()
-    path = os.environ.get("PTMI_LIB") or _build.LIB  # PTMI_LIB: an A/B build (_build.build_variant), as for the N-API addon
+    explicit = path is not None
+    path = path or os.environ.get("PTMI_LIB") or _build.LIB  # PTMI_LIB: an A/B build (_build.build_variant), as for the N-API addon
     if not os.path.exists(path):
-        raise OSError("libptmi.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc)")
+        raise OSError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc)" % os.path.basename(path))
     L = ctypes.CDLL(path)
     vp, i32, u32, sz, fp = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_size_t, ctypes.c_void_p
     L.ptmi_version.restype = i32
@@ -122,7 +127,10 @@ def load_library(build=False):
     L.ptmi_reduce_info.restype = ctypes.c_char_p
     L.ptmi_reduce_info.argtypes = [vp]
     L.ptmi_reload_tuning.argtypes = [vp]
-    _lib = L
+    if explicit:
+        _libs[path] = L
+    else:
+        _lib = L
     return L
 
 
@@ -196,8 +204,8 @@ class Context:
     """One integrator context (mirrors the reference's Renderer+WebGPU pair for the hot path).  `device` is a GPU index, or a
     list of them for a multi-device context (ptmi_create_multi: tiles sharded across the GPUs, one RCCL reduce on read-back)."""
 
-    def __init__(self, device=0):
-        self.lib = load_library()
+    def __init__(self, device=0, lib=None):
+        self.lib = lib if lib is not None else load_library()
         h = ctypes.c_void_p()
         if isinstance(device, (list, tuple)):
             ids = (ctypes.c_int * len(device))(*[int(d) for d in device])
