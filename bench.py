@@ -56,9 +56,11 @@ FETCH_MULT = {"k_bvh": 1.0}  # bytes per FETCH_SIZE byte, calibrated per access 
 GATHER_PEAK_RECORDS_PER_S = 223.5e9  # fallback; gather_peak() reads the probe's file
 GUIDE_MAX_CLOCK_GHZ = 2.4  # MI355X_MICROARCH.md "Max clock"
 N_CUS = 256
-# Is there a counter that tells DRAM from Infinity-Cache (MALL) traffic?  `rocprofv3 --list-avail` on the MI355X box (gfx950, ROCm 7.2) was searched for MALL / HBM / DRAM /
-# EA_*DRAM names in round 5 (profiles/r05_list_avail_mall.txt): see MALL_NOTE's text for what it offers.
-MALL_NOTE = "not separated: see profiles/r05_list_avail_mall.txt"
+# Is there a counter that tells DRAM from Infinity-Cache (MALL) traffic?  `rocprofv3 --list-avail` on the MI355X box (gfx950, ROCm 7.2) was searched in round 5
+# (profiles/r05_list_avail_mall.txt): no MALL hit / miss counter is exposed; TCC_EA0_{RD,WR}REQ_DRAM count requests DESTINED for DRAM (as opposed to GMI / IO) at the L2's
+# EA interface, upstream of the memory-side cache, where a MALL hit and a DRAM access look the same.
+MALL_NOTE = ("not separable on this box: rocprofv3 --list-avail (gfx950, ROCm 7.2; profiles/r05_list_avail_mall.txt) exposes no Infinity-Cache hit / miss counter — "
+             "TCC_EA0_*REQ_DRAM count requests destined for DRAM at the L2's EA interface, upstream of the memory-side cache — so the fabric bytes above are an upper bound on DRAM bytes")
 
 
 def gather_peak():
@@ -603,7 +605,10 @@ def watchdog(args):
             extra += ["--fallback-reason", why]
             if launched:
                 extra += ["--collective", "gather", "--host-collective"]
-                env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 1)  # the first rendezvous' store died with rank 0's child
+                # a rendezvous of its own: under torch.distributed.run the workers are clients of the launcher's store (TORCHELASTIC_USE_AGENT_STORE), which still
+                # holds whatever keys the first attempt's ranks wrote — so the fall-back's rank 0 starts a fresh store on another port instead
+                env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 17)
+                env["TORCHELASTIC_USE_AGENT_STORE"] = "False"
             else:
                 env["PTMI_MULTI_REDUCE"] = "copy"
         t0 = time.perf_counter()

@@ -6,7 +6,8 @@ in both scaling modes of bench.py: `weak` (spp x N: every rank keeps the rays of
 rays).  The step's collective cannot run on one GPU; its size is stated instead (bytes landing on the root per step, for the full-buffer reduce and for
 the gather of owned tiles), with the time they need at a stated per-link xGMI rate, so that the projected N-GPU figure = N x rays / (rank time + collective).
 
-usage (GPU box): tools/shard_sim.py [c2 c3]  -> gpurun_out/shard_sim.json (copied to profiles/r04_shard_sim.json)
+usage (GPU box): tools/shard_sim.py [c2 c3 c4 c5]  -> gpurun_out/shard_sim.json (copied to profiles/rNN_shard_sim.json).  c4 / c5 = configs[3] / configs[4], the two
+configurations BASELINE.json assigns to 8 GPUs (fixed totals: 512 spp at 1080p, 1024 spp at 4K): N = 1 and rank 0 of 8, strong.
 """
 import json
 import os
@@ -29,21 +30,24 @@ def main():
     out = {"note": __doc__.strip().splitlines()[0], "xgmi_link_gbs_assumed": XGMI_LINK_GBS, "rccl_reduce_busbw_gbs_assumed": RCCL_REDUCE_BUSBW_GBS,
            "collective_latency_ms_assumed": COLLECTIVE_LATENCY_MS, "tile_pixels": 4032, "workloads": {}}
     for w in workloads:
+        heavy = w in ("c4", "c5")  # seconds per step on one GPU: N = 1 and N = 8 strong only, fewer repetitions
+
         class A:
-            width, height, bounces, bvh, tris, stack_size, frames_in_flight = 1920, 1080, 8, "median", 0, 0, 0
+            width, height = (3840, 2160) if w == "c5" else (1920, 1080)
+            bounces, bvh, tris, stack_size, frames_in_flight = 8, "median", 0, 0, 0
         wl = bench.make_workload(pkg, w, A)
         ctx = bench.make_context(pkg, wl, 0, A)
         base_spp = bench.SPP[w]
         fb_bytes = A.width * A.height * 16
         rows = []
-        for world in (1, 2, 4, 8):
+        for world in ((1, 8) if heavy else (1, 2, 4, 8)):
             ctx.set_shard(0, world, 4032)
             for mode in ("weak", "strong"):
-                if world == 1 and mode == "strong":
+                if (world == 1 and mode == "strong") or (heavy and world > 1 and mode == "weak"):
                     continue
                 spp = base_spp * world if mode == "weak" else base_spp
                 ctx.clear(); ctx.render(wl["view"], 1, spp); ctx.synchronize(); ctx.reset_stats()
-                reps = 3 if w == "c2" else 2
+                reps = 3 if w == "c2" else 1 if (heavy and world == 1) else 2
                 t = time.perf_counter()
                 for _ in range(reps):
                     ctx.clear(); ctx.render(wl["view"], 1, spp); ctx.synchronize()

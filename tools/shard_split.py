@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Per-kernel times of ONE rank of an N-GPU render (rank 0 of N = 1, 4, 8; weak scaling: spp x N), a fresh context per N as a real rank has it
-(the placement search then sees the rank's own access pattern).  GPU box: python tools/shard_split.py [reuse] -> stdout"""
+"""Per-kernel times of ONE rank of an N-GPU render (rank 0 of N = 1, 4, 8; weak scaling: spp x N, or MODE=strong: the fixed total), a fresh context per N as a real
+rank has it (the placement search then sees the rank's own access pattern).  GPU box: [MODE=strong] [WORLDS=1,8] [WL=c2] python tools/shard_split.py [reuse] -> stdout"""
 import os
 import sys
 import time
@@ -26,13 +26,13 @@ for w in os.environ.get("WL", "c2,c3").split(","):
         if not reuse:
             ctx = bench.make_context(pkg, wl, 0, A)
         ctx.set_shard(0, world, TILE)
-        spp = bench.SPP[w] * world
+        spp = bench.SPP[w] * (1 if os.environ.get("MODE") == "strong" else world)
         ctx.set_timing(1)
         ctx.clear(); ctx.render(wl["view"], 1, spp); ctx.synchronize(); ctx.reset_stats()
         ctx.clear(); t = time.perf_counter(); ctx.render(wl["view"], 1, spp); ctx.synchronize(); dt = time.perf_counter() - t
         st = ctx.stats()
         print(w, "world", world, "spp", spp, "wall %.2f ms" % (dt * 1e3), {k: round(st[k], 2) for k in ("generate_ms", "bvh_ms", "shade_ms", "tail_ms", "accumulate_ms")},
-              "launches", st["generate_launches"], st["intersect_launches"], st["accumulate_launches"], "placement sets", st["placement_sets"], flush=True)
+              "launches", st["generate_launches"], st["intersect_launches"], st["tail_launches"], st["accumulate_launches"], "placement sets", st["placement_sets"], "(%.0f ms)" % st["placement_ms"], flush=True)
         if not reuse:
             ctx.close()
     if reuse:

@@ -486,6 +486,39 @@ static void obj_parse_lines(const char* p, const char* end, ObjChunk& c) {
   }
 }
 
+// Runs fn(0) .. fn(n - 1), fn(0) on the calling thread and the others on threads of their own.  Nothing a worker throws leaves its thread (an exception escaping a
+// std::thread is std::terminate: the host process, not a status code), every started thread is joined on every way out — also when starting one fails —, and the
+// first failure is what the caller gets: false = some worker threw (out of memory, in practice).
+template <class F>
+static bool run_workers(unsigned n, F fn) {
+  std::vector<char> failed(n, 0);
+  auto guarded = [&](unsigned k) {
+    try {
+      fn(k);
+    } catch (...) {
+      failed[k] = 1;
+    }
+  };
+  struct Joiner {
+    std::vector<std::thread> th;
+    ~Joiner() {
+      for (auto& t : th)
+        if (t.joinable()) t.join();
+    }
+  } j;
+  bool ok = true;
+  try {
+    j.th.reserve(n);
+    for (unsigned k = 1; k < n; k++) j.th.emplace_back(guarded, k);
+  } catch (...) {  // no thread to be had: the chunks without one are done here
+    for (unsigned k = (unsigned)j.th.size() + 1; k < n; k++) guarded(k);
+  }
+  guarded(0);
+  for (auto& t : j.th) t.join();
+  for (char f : failed) ok = ok && !f;
+  return ok;
+}
+
 static unsigned host_threads(size_t work_items, size_t per_thread) {
   unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   if (const char* e = getenv("PTMI_BUILD_THREADS")) hw = (unsigned)std::max(1, atoi(e));
@@ -511,14 +544,8 @@ extern "C" int ptmi_obj_parse(const char* text, size_t len, float** vertices_out
       cut[k] = nl ? nl + 1 : end;
     }
     std::vector<ObjChunk> chunks(nt);
-    {
-      std::vector<std::thread> th;
-      // (a run that ends just behind a '\n' sees one empty extra line at its end: ignored like every empty line)
-      auto run = [&](unsigned k) { obj_parse_lines(cut[k], cut[k + 1], chunks[k]); };
-      for (unsigned k = 1; k < nt; k++) th.emplace_back(run, k);
-      run(0);
-      for (auto& t : th) t.join();
-    }
+    // (a run that ends just behind a '\n' sees one empty extra line at its end: ignored like every empty line)
+    if (!run_workers(nt, [&](unsigned k) { obj_parse_lines(cut[k], cut[k + 1], chunks[k]); })) return PTMI_ERR_NO_MEMORY;
     ObjRows V, N;
     std::vector<double> vidx, nidx;
     if (nt == 1) {
@@ -552,12 +579,7 @@ extern "C" int ptmi_obj_parse(const char* text, size_t len, float** vertices_out
           c += valid(idx[i]) ? (size_t)(R.offset[(size_t)idx[i] + 1] - R.offset[(size_t)idx[i]]) : 1;
         start[k + 1] = c;
       };
-      {
-        std::vector<std::thread> th;
-        for (unsigned k = 1; k < nt; k++) th.emplace_back(count, k);
-        count(0);
-        for (auto& t : th) t.join();
-      }
+      if (!run_workers(nt, count)) return PTMI_ERR_NO_MEMORY;
       for (unsigned k = 0; k < nt; k++) start[k + 1] += start[k];
       *n = start[nt];
       if (*n == 0) return PTMI_OK;
@@ -574,11 +596,9 @@ extern "C" int ptmi_obj_parse(const char* text, size_t len, float** vertices_out
           for (uint32_t j = R.offset[r]; j < R.offset[r + 1]; j++) *o++ = (float)R.data[j];
         }
       };
-      {
-        std::vector<std::thread> th;
-        for (unsigned k = 1; k < nt; k++) th.emplace_back(fill, k);
-        fill(0);
-        for (auto& t : th) t.join();
+      if (!run_workers(nt, fill)) {
+        free(flat);
+        return PTMI_ERR_NO_MEMORY;
       }
       *out = flat;
       return PTMI_OK;
