@@ -3,6 +3,8 @@ and work counters on seeded inputs, plus size-independent properties at BASELINE
 
 Tolerance: north_star asks for per-pixel L2 < 1e-4; the build targets and tests BIT-EXACT equality
 (NaNs compared as NaN), which implies it."""
+import os
+
 import numpy as np
 import pytest
 
@@ -73,6 +75,11 @@ def test_framebuffer_bit_exact(ctx, pkg, oracle, name, cam, w, h, frames, params
     assert_same_bits(got, want, name)
     for k in ("rays", "paths", "node_visits", "tri_tests", "sphere_tests", "quad_tests", "mat_fetches"):
         assert st[k] == ost[k], (k, st[k], ost[k])
+    # ... and through the kernels WITHOUT counters — the ones every timed run uses: since round 5 they test the quads in fewer, fuller passes (hit_quads,
+    # csrc/ptmi_device.h: parallel quads facing each other's way share a pass) where the counted ones keep the reference's loop as it stands
+    ctx.clear()
+    ctx.render(view, 1, frames)
+    assert_same_bits(ctx.read_framebuffer(), want, name + " (uncounted kernels)")
 
 
 def test_render_frame_equals_batched_render_and_reset(ctx, pkg, oracle):
@@ -119,6 +126,76 @@ def test_hit_records_bit_exact(ctx, pkg, oracle, name):
         assert_same_bits(got[f][m], want[f][m], f"{name}.{f}")
     assert np.array_equal(got["front_face"][m], want["front_face"][m])
     assert np.array_equal(grng, wrng)  # hit_volume's RNG draws (common.wgsl:134) happen at the same points
+
+
+def test_quads_in_shared_passes_hit_records(ctx, pkg, oracle):
+    """hit_quads (csrc/ptmi_device.h, round 5): quads whose stored normals are exact negatives share a pass, the others keep one of their own, and the accepted quad is
+    the one with the smallest t, the lowest index among equal t — against the oracle's loop in the reference's order (hitRay.wgsl:33-40), per ray.  The scene is built to
+    hit every seam: a second floor in the floor's plane (equal t: the lower index must win), a quad back to back with the floor (same plane, opposite normal: a
+    pair with no gap), a third quad parallel to a pair (stays single), free quads at odd angles; rays that start ON planes and edges, axis-aligned and zero
+    directions, and non-finite ones (the wave must fall back to the loop in order: a NaN t is ACCEPTED by the shader's comparisons and poisons closest_so_far)."""
+    from webgpu_path_tracer_amd.scenes import CornellScene
+
+    class QuadScene(CornellScene):
+        def create_quads(self):
+            super().create_quads()  # light, back, left, right, ceiling, floor: two pairs + two singles
+            d = self.material_dict
+            extra = [
+                ([-1, -1, -1], [2, 0, 0], [0, 0, 2], "red"),          # the floor's plane once more, same way up: ties in t, index decides
+                ([-1, -1, 1], [2, 0, 0], [0, 0, -2], "green"),        # the floor's plane, facing DOWN: back to back with the floor
+                ([-0.5, -0.2, -0.5], [1, 0, 0], [0, 0, 1], "blue"),   # a shelf parallel to floor and ceiling
+                ([-0.5, -0.2, 0.5], [1, 0, 0], [0, 0, -1], "white"),  # ... and its underside, a little smaller
+                ([-0.8, -0.9, 0.2], [0.7, 0.5, 0.1], [-0.1, 0.6, 0.4], "glossywhite"),
+                ([0.3, -0.6, -0.4], [0.2, 0.0, 0.9], [0.5, 0.5, 0.0], "black"),
+            ]
+            for q, u, v, m in extra:
+                self.add_quad(q, u, v, d[m])
+                self.objs.append(self.quads[-1])
+
+    b = QuadScene().buffers(native=pkg.ptmi.NativeHost())
+    assert b["quads"].size // 20 == 12
+    ctx.upload_scene(b)
+    ctx.set_params()
+    rng = np.random.default_rng(41)
+    rays = _rays(rng, 12000)
+    n = 6000
+    o = rng.uniform(-1, 1, (n, 3))
+    o[rng.random(n) < 0.5, 1] = -1.0                 # on the floor's plane (three quads there)
+    o[rng.random(n) < 0.2, 0] = rng.choice([-1.0, 1.0, -0.5, 0.5])  # on wall planes / the shelf's edges
+    o[rng.random(n) < 0.2, 1] = -0.2                 # on the shelf's plane
+    d = rng.normal(0, 1, (n, 3))
+    k = rng.integers(0, 3, n)
+    axis = rng.random(n) < 0.3
+    d[axis] = 0.0
+    d[axis, k[axis]] = rng.choice([-1.0, 1.0], axis.sum())   # axis-aligned: parallel to two of the three wall pairs
+    d[rng.random(n) < 0.05] = 0.0                    # zero direction (scattered = Ray(0, 0))
+    special = np.concatenate([o, d], 1).astype(np.float32)
+    bad = special[:64].copy()                        # one wave's worth with NaN / inf sprinkled in: the in-order fallback
+    bad[::5, 3] = np.nan
+    bad[1::7, 0] = np.inf
+    bad[3::11, 4] = -np.inf
+    rays = np.concatenate([rays, special, bad]).astype(np.float32)
+    seeds = rng.integers(0, 2**32, rays.shape[0], dtype=np.uint64).astype(np.uint32)
+    got, _ = ctx.trace(rays, seeds)
+    want, _, _ = oracle.hit_scene(b, rays, seeds)
+    assert np.array_equal(got["hit"], want["hit"])
+    m = want["hit"] == 1
+    assert m.sum() > 10000
+    for f in ("t", "p", "normal", "material"):
+        assert_same_bits(got[f][m], want[f][m], "quad scene " + f)
+    assert np.array_equal(got["front_face"][m], want["front_face"][m])
+    # the pictures too (k_generate, k_shade's flush pass and k_tail all run hit_quads; the `pipeline` fixture brings each of them in turn), with and without counters
+    view = cornell_view(pkg)
+    ctx.set_params(max_bounces=8)
+    ctx.resize(160, 120)
+    want_fb, _ = oracle.render(b, 160, 120, view, 1, 3, max_bounces=8)
+    for counters in (False, True):
+        ctx.set_counters(counters)
+        ctx.clear()
+        ctx.render(view, 1, 3)
+        got_fb = ctx.read_framebuffer()
+        ctx.set_counters(False)
+        assert_same_bits(got_fb, want_fb, "quad scene rendered (counters %s)" % counters)
 
 
 def test_degenerate_rays(ctx, pkg, oracle):
@@ -499,6 +576,9 @@ def test_random_scenes_bit_exact(ctx, pkg, oracle, seed):
     assert_same_bits(got, want, "random scene %d %r" % (seed, params))
     for k in ("rays", "paths", "node_visits", "tri_tests", "sphere_tests", "quad_tests", "mat_fetches"):
         assert st[k] == ost[k], (seed, k, st[k], ost[k])
+    ctx.clear()  # the uncounted kernels (hit_quads in shared passes; free quads at any angle, some of them nearly parallel)
+    ctx.render(view, 1 + seed, 3)
+    assert_same_bits(ctx.read_framebuffer(), want, "random scene %d, uncounted kernels" % seed)
 
 
 @pytest.mark.parametrize("seed", [2, 5, 11])
@@ -531,6 +611,9 @@ def test_unknown_material_types_bit_exact(ctx, pkg, oracle, seed):
     assert_same_bits(got, want, "unknown material types, scene %d" % seed)
     for k in ("rays", "paths", "node_visits", "tri_tests", "sphere_tests", "quad_tests", "mat_fetches"):
         assert st[k] == ost[k], (seed, k, st[k], ost[k])
+    ctx.clear()  # the uncounted kernels: rays with a zero or NaN direction (scattered = Ray(0, 0)) must take hit_quads' in-order loop
+    ctx.render(view, 3, 3)
+    assert_same_bits(ctx.read_framebuffer(), want, "unknown material types, scene %d, uncounted kernels" % seed)
 
 
 def test_device_bvh_builder_is_byte_identical_to_host(ctx, pkg):

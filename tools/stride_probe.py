@@ -16,6 +16,7 @@ import bench  # noqa: E402
 pkg = entry._load_pkg()
 sizes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:] if "x" in a] or [(1920, 1080), (2048, 1024), (2048, 1023), (2048, 1025), (1024, 1024), (1024, 1023)]
 reps = int(os.environ.get("REPS", "3"))
+shard = os.environ.get("SHARD")  # "world:tile": rank 0 of `world` with tiles of `tile` pixels, spp x world (one rank of a weak-scaled run: profiles/r04_shard_tile.txt)
 out = []
 for W, H in sizes:
     class A:
@@ -24,6 +25,10 @@ for W, H in sizes:
     for rep in range(reps):
         ctx = bench.make_context(pkg, wl, 0, A)
         spp = 64
+        if shard:
+            world, tile = (int(x) for x in shard.split(":"))
+            ctx.set_shard(0, world, tile)
+            spp = 64 * world
         ctx.clear(); ctx.render(wl["view"], 1, spp); ctx.synchronize()
         ctx.reset_stats(); ctx.set_timing(1)
         ctx.clear(); ctx.render(wl["view"], 1, spp); ctx.synchronize()
