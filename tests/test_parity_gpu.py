@@ -75,8 +75,7 @@ def test_framebuffer_bit_exact(ctx, pkg, oracle, name, cam, w, h, frames, params
     assert_same_bits(got, want, name)
     for k in ("rays", "paths", "node_visits", "tri_tests", "sphere_tests", "quad_tests", "mat_fetches"):
         assert st[k] == ost[k], (k, st[k], ost[k])
-    # ... and through the kernels WITHOUT counters — the ones every timed run uses: since round 5 they test the quads in fewer, fuller passes (hit_quads,
-    # csrc/ptmi_device.h: parallel quads facing each other's way share a pass) where the counted ones keep the reference's loop as it stands
+    # ... and through the kernels WITHOUT counters — the ones every timed run uses (other template instances of the same code)
     ctx.clear()
     ctx.render(view, 1, frames)
     assert_same_bits(ctx.read_framebuffer(), want, name + " (uncounted kernels)")
@@ -128,12 +127,11 @@ def test_hit_records_bit_exact(ctx, pkg, oracle, name):
     assert np.array_equal(grng, wrng)  # hit_volume's RNG draws (common.wgsl:134) happen at the same points
 
 
-def test_quads_in_shared_passes_hit_records(ctx, pkg, oracle):
-    """hit_quads (csrc/ptmi_device.h, round 5): quads whose stored normals are exact negatives share a pass, the others keep one of their own, and the accepted quad is
-    the one with the smallest t, the lowest index among equal t — against the oracle's loop in the reference's order (hitRay.wgsl:33-40), per ray.  The scene is built to
-    hit every seam: a second floor in the floor's plane (equal t: the lower index must win), a quad back to back with the floor (same plane, opposite normal: a
-    pair with no gap), a third quad parallel to a pair (stays single), free quads at odd angles; rays that start ON planes and edges, axis-aligned and zero
-    directions, and non-finite ones (the wave must fall back to the loop in order: a NaN t is ACCEPTED by the shader's comparisons and poisons closest_so_far)."""
+def test_quad_seams_hit_records(ctx, pkg, oracle):
+    """hit_quad's seams (hitRay.wgsl:33-40, common.wgsl:148-187), per ray against the oracle: a second floor in the floor's plane (equal t: the lower index keeps the
+    hit), a quad back to back with the floor (same plane, opposite normal), parallel quads, free quads at odd angles; rays that start ON planes and edges, axis-aligned
+    and zero directions, and non-finite ones (a NaN t is ACCEPTED by the shader's comparisons and then poisons closest_so_far: the order of the tests shows).
+    (Written for round 5's shared-pass experiment on hit_quads — csrc/ptmi_device.h — and kept: any reordering of the quad tests has to pass it.)"""
     from webgpu_path_tracer_amd.scenes import CornellScene
 
     class QuadScene(CornellScene):
@@ -576,7 +574,7 @@ def test_random_scenes_bit_exact(ctx, pkg, oracle, seed):
     assert_same_bits(got, want, "random scene %d %r" % (seed, params))
     for k in ("rays", "paths", "node_visits", "tri_tests", "sphere_tests", "quad_tests", "mat_fetches"):
         assert st[k] == ost[k], (seed, k, st[k], ost[k])
-    ctx.clear()  # the uncounted kernels (hit_quads in shared passes; free quads at any angle, some of them nearly parallel)
+    ctx.clear()  # the uncounted kernels
     ctx.render(view, 1 + seed, 3)
     assert_same_bits(ctx.read_framebuffer(), want, "random scene %d, uncounted kernels" % seed)
 
@@ -611,7 +609,7 @@ def test_unknown_material_types_bit_exact(ctx, pkg, oracle, seed):
     assert_same_bits(got, want, "unknown material types, scene %d" % seed)
     for k in ("rays", "paths", "node_visits", "tri_tests", "sphere_tests", "quad_tests", "mat_fetches"):
         assert st[k] == ost[k], (seed, k, st[k], ost[k])
-    ctx.clear()  # the uncounted kernels: rays with a zero or NaN direction (scattered = Ray(0, 0)) must take hit_quads' in-order loop
+    ctx.clear()  # the uncounted kernels (rays with a zero or NaN direction: scattered = Ray(0, 0))
     ctx.render(view, 3, 3)
     assert_same_bits(ctx.read_framebuffer(), want, "unknown material types, scene %d, uncounted kernels" % seed)
 

@@ -153,8 +153,7 @@ struct ptmi_ctx {
   std::vector<int32_t> h_meshes;
   bool scene_dirty = true;
 
-  DBuf d_quad_unit_n, d_quad_sched;
-  int n_quad_slots = 0;
+  DBuf d_quad_unit_n;
   // ptmi_build_scene_bvh: the BVH rows (binding 9's layout) live on the device only — no host copy, pair64 made there too
   DBuf d_bvh_rows;
   bool bvh_on_device = false;
@@ -516,28 +515,6 @@ int prepare_scene(ptmi_ctx* c) {
   HIP_TRY(c, up(c->d_sphere_info, sphere_info.data(), sphere_info.size() * 4));
   HIP_TRY(c, up(c->d_quads, c->h_quads.data(), c->h_quads.size() * 4));
   HIP_TRY(c, up(c->d_quad_mat, quad_mat.data(), quad_mat.size() * 4));
-  {
-    // hit_quads' schedule (ptmi_device.h): quads whose stored normals are exact negatives of each other share a pass.  A quad is paired with the first later quad that
-    // qualifies; slots in the order of their first quad.  Any non-finite or huge number in the table turns the schedule off (n_quad_slots = -1).
-    std::vector<int32_t> sched;
-    std::vector<char> used((size_t)n_quad, 0);
-    bool sane = true;
-    for (size_t k = 0; k < c->h_quads.size() && sane; k++) sane = std::fabs(c->h_quads[k]) < 1e18f;  // (false for NaN)
-    for (int i = 0; i < n_quad && sane; i++) {
-      if (used[i]) continue;
-      const float* ni = &c->h_quads[20 * (size_t)i + 12];
-      int partner = -1;
-      for (int j = i + 1; j < n_quad && partner < 0; j++) {
-        const float* nj = &c->h_quads[20 * (size_t)j + 12];
-        if (!used[j] && nj[0] == -ni[0] && nj[1] == -ni[1] && nj[2] == -ni[2] && (ni[0] != 0.0f || ni[1] != 0.0f || ni[2] != 0.0f)) partner = j;
-      }
-      if (partner >= 0) used[partner] = 1;
-      sched.push_back(i);
-      sched.push_back(partner);
-    }
-    c->n_quad_slots = sane ? (int)(sched.size() / 2) : -1;
-    HIP_TRY(c, up(c->d_quad_sched, sched.data(), sched.size() * 4));
-  }
   HIP_TRY(c, c->d_quad_unit_n.ensure(std::max<size_t>((size_t)n_quad * 16, 16)));
   if (n_quad > 0) {
     hipLaunchKernelGGL(k_quad_digest, dim3((unsigned)((n_quad + 63) / 64)), dim3(64), 0, c->stream, c->d_quads.as<float4>(), n_quad, c->d_quad_unit_n.as<float4>());
@@ -575,8 +552,6 @@ int prepare_scene(ptmi_ctx* c) {
   S.quads = c->d_quads.as<float4>();
   S.quad_mat = c->d_quad_mat.as<int>();
   S.quad_unit_n = c->d_quad_unit_n.as<float4>();
-  S.quad_sched = c->d_quad_sched.as<int2>();
-  S.n_quad_slots = c->n_quad_slots;
   S.tris = c->d_tris.as<float4>();
   S.pretri = c->d_pretri.as<float4>();
   S.trinorm = c->d_trinorm.as<float4>();
@@ -1532,7 +1507,7 @@ void ptmi_destroy(ptmi_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   drain_spans(c);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
-  for (DBuf* b : {&c->d_quad_unit_n, &c->d_quad_sched, &c->d_spheres, &c->d_sphere_info, &c->d_quads, &c->d_quad_mat, &c->d_tris, &c->d_pretri, &c->d_trinorm, &c->d_meshes, &c->d_xforms,
+  for (DBuf* b : {&c->d_quad_unit_n, &c->d_spheres, &c->d_sphere_info, &c->d_quads, &c->d_quad_mat, &c->d_tris, &c->d_pretri, &c->d_trinorm, &c->d_meshes, &c->d_xforms,
                   &c->d_mats, &c->d_pairs, &c->d_leaf_table, &c->d_fb_own, &c->d_q0[0], &c->d_q0[1], &c->d_q1[0], &c->d_q1[1], &c->d_q2[0],
                   &c->d_q2[1], &c->d_tp[0], &c->d_tp[1], &c->d_hm[0], &c->d_hm[1], &c->d_uv, &c->d_acc, &c->d_pixsum, &c->d_touched, &c->d_ctl, &c->d_totals,
                   &c->d_scratch, &c->d_spill, &c->d_heads, &c->d_fb_gather, &c->d_fb_stage, &c->d_bvh_rows, &c->d_carry[0], &c->d_carry[1]})

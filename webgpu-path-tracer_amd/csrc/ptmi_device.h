@@ -252,9 +252,6 @@ struct DevScene {
   const int2* sphere_info;  // {material word, is_volume}
   const float4* quads;  // 5 float4 / quad
   const int* quad_mat;      // material word per quad
-  const int2* quad_sched;   // hit_quads' schedule (prepare_scene): {i, j} = quads i and j lie in parallel planes facing each other's way (normal_j == -normal_i exactly) and are
-                            // tested in ONE pass — every ray faces exactly one of the two —, {i, -1} = quad i on its own; slots in the order of their first quad
-  int n_quad_slots;         // -1: no schedule (a quad with non-finite or huge numbers): the reference's loop as it stands
   const float4* trinorm;      // 3 x float4 per triangle: the vertex normals nA, nB, nC (common.wgsl:230) with the mesh's transform index in nA.w — what
                               // resolve_hit needs of a triangle hit in one 48-byte run (the raw 96-byte record + the pretri record: three cache lines)
   const float4* quad_unit_n;  // normalize(quad.normal), evaluated once per quad by k_quad_digest with the very same norm3()
@@ -495,9 +492,14 @@ DEV void hit_spheres(const DevScene& S, f3 o, f3 d, uint32_t& rng, Closest& c, C
   }
 }
 
-// shaders/hitRay.wgsl:33-40 with hit_quad (common.wgsl:148-187): the reference's loop as it stands — quad after quad, closest_so_far shrinking on the way.
+// shaders/hitRay.wgsl:33-40 with hit_quad (common.wgsl:148-187)
+// (Round 5 tried the quads in fewer, fuller passes — the loop's result is the accepted quad with the smallest t, the lowest index among equal t, so the order of the tests is
+// free for finite rays; quads in parallel planes with exactly opposite normals (the walls of every scene the reference ships) then share ONE pass in which every lane works on
+// the one it faces.  Bit-exact through the whole parity suite, and no faster: k_shade 7.6 -> 7.7 ms on configs[1] (the selects between two scalar-resident quad records — one
+// SGPR operand per VALU instruction on gfx9 — and the finite-ray guard cost what the merged pass saves), k_generate 1.18 -> 1.48 ms (its coherent waves skip a back-facing wall
+// as a whole in this loop; a shared pass never can).  profiles/r05_quad_pairs_ab.txt; the code is in the history (commit "Experiment: hit_quads ...").)
 template <bool COUNT>
-DEV void hit_quads_in_order(const DevScene& S, f3 o, f3 d, Closest& c, Counters& cn) {
+DEV void hit_quads(const DevScene& S, f3 o, f3 d, Closest& c, Counters& cn) {
   for (int i = 0; i < S.n_quads; i++) {
     const float4* q = S.quads + 5 * i;
     // the whole 80-byte record and the material id at once: scalar loads, one wait
@@ -525,72 +527,6 @@ DEV void hit_quads_in_order(const DevScene& S, f3 o, f3 d, Closest& c, Counters&
     c.prim = (K_QUAD << 28) | (uint32_t)i;
     c.mat = qmat;
     if (COUNT) cn.mat_fetches++;
-  }
-}
-
-// The same result from fewer, fuller passes (round 5).  What the loop above returns for a ray whose origin and direction are finite is the accepted quad with the smallest
-// t below the closest_so_far it started with, the lowest index among equal t — the order of the tests only decides how much is pruned on the way —, so the order is free.
-// Quads i, j in parallel planes that face each other's way (normal_j == -normal_i: the side walls, floor and ceiling of every scene the reference ships) go through ONE
-// pass: dot(d, n_j) = -dot(d, n_i) and dot(n_j, o) = -dot(n_i, o) bit for bit (IEEE products and sums are odd functions; only a zero's sign can differ, and zeros are
-// rejected), so a ray is front-facing to exactly one of the two, and every lane works on the one it faces — where the loop above ran two passes with half the lanes each
-// (profiles/NOTES_r04.md §1: three quarters of k_shade's idle lane-instructions).  A non-finite ray (NaN t is ACCEPTED by the shader's comparisons and then poisons
-// closest_so_far: order matters) sends the whole wave through the loop above; so do the counted kernels (mat_fetches counts the acceptances on the way).
-template <bool COUNT>
-DEV void hit_quads(const DevScene& S, f3 o, f3 d, Closest& c, Counters& cn) {
-  // (|components| summed: NaN and inf propagate, and below 1e18 no product with a quad's numbers — themselves below 1e18, prepare_scene — can overflow into a NaN)
-  const float mag = ((((ptm_abs(o.x) + ptm_abs(o.y)) + ptm_abs(o.z)) + ptm_abs(d.x)) + ptm_abs(d.y)) + ptm_abs(d.z);
-  if (COUNT || S.n_quad_slots < 0 || __ballot(!(mag < 1e18f)) != 0ull) {
-    hit_quads_in_order<COUNT>(S, o, d, c, cn);
-    return;
-  }
-  int best = -1;  // the quad c.t comes from; -1: none yet (c.t is what the spheres left)
-  for (int s = 0; s < S.n_quad_slots; s++) {
-    const int2 sl = ldu(S.quad_sched + s);
-    const float4* q = S.quads + 5 * sl.x;
-    const float4 q3 = ldu(q + 3);
-    const f3 n = mk3(q3);
-    LT(LT_QUAD_LOOP);
-    const float sd = dot3(d, n);
-    float denom, num;
-    bool other = false;
-    if (sl.y < 0) {
-      if (sd > 0) continue;
-      LT(LT_QUAD_FRONT);
-      denom = dot3(n, d);
-      if (ptm_abs(denom) < 1e-8f) continue;
-      num = q3.w - dot3(n, o);
-    } else {
-      other = sd > 0;  // back-facing to i = front-facing to j
-      LT(LT_QUAD_FRONT);
-      denom = other ? -sd : sd;  // dot(n_j, d)
-      if (ptm_abs(denom) < 1e-8f) continue;
-      const float p = dot3(n, o), dj = ldu(S.quads + 5 * sl.y + 3).w;
-      num = other ? (dj + p) : (q3.w - p);  // D_j - dot(n_j, o) = D_j - (-p)
-    }
-    LT(LT_QUAD_DENOM);
-    const float t = num / denom;
-    if (t <= S.tmin || t > c.t) continue;  // (t == c.t: a tie between two quads goes to the lower index, below)
-    LT(LT_QUAD_T);
-    float4 q0 = ldu(q), q1 = ldu(q + 1), q2 = ldu(q + 2), q4 = ldu(q + 4);
-    int idx = sl.x, qmat = ldu(S.quad_mat + sl.x);
-    if (sl.y >= 0) {
-      const float4* r = S.quads + 5 * sl.y;
-      const float4 r0 = ldu(r), r1 = ldu(r + 1), r2 = ldu(r + 2), r4 = ldu(r + 4);
-      const int rmat = ldu(S.quad_mat + sl.y);
-      if (other) q0 = r0, q1 = r1, q2 = r2, q4 = r4, idx = sl.y, qmat = rmat;
-    }
-    if (t == c.t && !(best >= 0 && idx < best)) continue;
-    const f3 isect = o + t * d;
-    const f3 ph = isect - mk3(q0);
-    const f3 w = mk3(q4);
-    const float alpha = dot3(w, cross3(ph, mk3(q2)));
-    const float beta = dot3(w, cross3(mk3(q1), ph));
-    if (alpha < 0 || 1 < alpha || beta < 0 || 1 < beta) continue;
-    LT(LT_QUAD_ACCEPT);
-    c.t = t;
-    c.prim = (K_QUAD << 28) | (uint32_t)idx;
-    c.mat = qmat;
-    best = idx;
   }
 }
 
