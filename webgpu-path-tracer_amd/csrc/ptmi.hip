@@ -26,7 +26,6 @@ using namespace ptmi;
 int ptmi_bvhdev_build_scene(void* stream, const float* d_tris, uint32_t n, const int32_t* h_meshes, int n_meshes, const float* h_xforms, int n_xforms, float* d_rows,
                             float* d_tris_out, int* depth_out, uint32_t* bad_tri, int sah, uint32_t* n_nodes_out);
 int ptmi_bvhdev_make_pairs(void* stream, const float* d_rows, uint32_t nn, float* d_pairs, int* d_leaf_table, uint32_t* n_multi);
-int ptmi_bvhdev_make_wide(void* stream, const float* d_pairs, uint32_t n_inner, float* d_wide);
 
 namespace {
 
@@ -126,7 +125,6 @@ struct Tuning {
   int refill = kRefillThreshold, leaf_batch = kLeafBatch, bvh_range = (int)kBvhRange;  // PTMI_REFILL, PTMI_LEAF_BATCH, PTMI_BVH_RANGE
   int tail_waves_per_cu = 0;   // PTMI_TAIL_WAVES_PER_CU (0 = 16, or 24 for the 6-wave build)
   bool tail6 = true;           // PTMI_TAIL6=0: never the 80-VGPR build of k_tail
-  bool bvh_wide = false;       // PTMI_BVH_WIDE=1: k_bvh walks two levels of the tree per fetch (round 5's experiment; NOABORT trees, uncounted kernels)
   int bvh_carry = 32;          // PTMI_BVH_CARRY: iterations a k_bvh wave goes on after the queue is exhausted before it carries its unfinished rays into the next
                                // step's queue (Carry, ptmi_device.h); 0 = never (every launch traces its longest ray to the end)
   int bvh_carry_slots = 1 << 18;  // PTMI_BVH_CARRY_SLOTS: the queues' carry prefix
@@ -164,7 +162,7 @@ struct ptmi_ctx {
   bool bvh_dev_sah = false;  // built by ptmi_build_scene_bvh_sah
   bool bvh_dev_stale = false;  // triangles / meshes / transforms were uploaded after the build: its boxes and leaf order describe another scene
   int bvh_dev_depth = 0;
-  DBuf d_spheres, d_sphere_info, d_quads, d_quad_mat, d_tris, d_pretri, d_trinorm, d_meshes, d_xforms, d_mats, d_pairs, d_wide, d_leaf_table;
+  DBuf d_spheres, d_sphere_info, d_quads, d_quad_mat, d_tris, d_pretri, d_trinorm, d_meshes, d_xforms, d_mats, d_pairs, d_leaf_table;
   DevScene S{};
   int bvh_depth = 0;             // max number of inner nodes on a root-to-leaf path
   bool has_unknown_material = false;
@@ -547,14 +545,6 @@ int prepare_scene(ptmi_ctx* c) {
   if (!pairs_on_device) HIP_TRY(c, up(c->d_pairs, pairs.data(), pairs.size() * 4));
   if (!(pairs_on_device && c->bvh_dev_sah)) HIP_TRY(c, up(c->d_leaf_table, leaf_table.data(), leaf_table.size() * 4));
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // the staging vectors die at scope exit
-  c->S.wide = nullptr;
-  if (c->tun.bvh_wide && n_node > 1) {
-    const size_t n_inner = (size_t)(n_node - 1) / 2;
-    HIP_TRY(c, c->d_wide.ensure(n_inner * 128));
-    const int e = ptmi_bvhdev_make_wide((void*)c->stream, c->d_pairs.as<float>(), (uint32_t)n_inner, c->d_wide.as<float>());
-    if (e) return fail(c, PTMI_ERR_DEVICE, std::string("wide records: ") + hipGetErrorString((hipError_t)e));
-    c->S.wide = c->d_wide.as<float4>();
-  }
 
   DevScene& S = c->S;
   S.spheres = c->d_spheres.as<float4>();
@@ -733,11 +723,7 @@ const void* shade_kernel(bool is, bool so, bool cn, bool mu) {
   return nullptr;
 }
 
-int stack_alloc_for(const ptmi_ctx* c) {
-  const int binary = std::max(1, std::min(c->prm.stack_size, std::max(c->bvh_depth, 1)));
-  // (the wide walk — PTMI_BVH_WIDE, NOABORT trees only — pushes up to three entries per two levels)
-  return c->S.wide ? std::max(binary, 3 * ((c->bvh_depth + 1) / 2) + 1) : binary;
-}
+int stack_alloc_for(const ptmi_ctx* c) { return std::max(1, std::min(c->prm.stack_size, std::max(c->bvh_depth, 1))); }
 
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -754,7 +740,6 @@ void load_tuning(ptmi_ctx* c) {
   t.bvh_range = std::max(64, std::min(1 << 16, env_int("PTMI_BVH_RANGE", t.bvh_range))) & ~63;
   t.tail_waves_per_cu = std::max(0, std::min(32, env_int("PTMI_TAIL_WAVES_PER_CU", t.tail_waves_per_cu)));
   t.tail6 = env_int("PTMI_TAIL6", 1) != 0;
-  t.bvh_wide = env_int("PTMI_BVH_WIDE", 0) != 0;
   t.bvh_carry = std::max(0, env_int("PTMI_BVH_CARRY", t.bvh_carry));
   t.bvh_carry_slots = std::max(64, std::min(1 << 22, env_int("PTMI_BVH_CARRY_SLOTS", t.bvh_carry_slots)));
   t.bvh_carry_last = std::max(0, env_int("PTMI_BVH_CARRY_LAST", t.bvh_carry_last));
@@ -808,20 +793,17 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
   // step 0's queue does not store the rays' common origin (k_generate): the kernel is handed cam_origin
   float4 cam = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   if (first_rc) cam = make_float4(first_rc->cam_o[0], first_rc->cam_o[1], first_rc->cam_o[2], 1.0f);
-#define PTMI_LAUNCH_BVH_W(CNT, NA, WI)                                                                                                                                 \
-  hipLaunchKernelGGL((k_bvh2<CNT, NA, WI>), dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), n_teams, c->prm.stack_size, le, se, \
+#define PTMI_LAUNCH_BVH(CNT, NA)                                                                                                                                       \
+  hipLaunchKernelGGL((k_bvh2<CNT, NA>), dim3(grid), dim3(64), lds, c->stream, c->S, P, ctl, c->d_heads.as<uint32_t>(), n_teams, c->prm.stack_size, le, se, \
                      c->d_spill.as<int2>(), thr, leaf_batch, tot, range_cap, cam, cy)
-#define PTMI_LAUNCH_BVH(CNT, NA) PTMI_LAUNCH_BVH_W(CNT, NA, false)
   if (c->counters) {
     if (noabort) PTMI_LAUNCH_BVH(true, true);
     else PTMI_LAUNCH_BVH(true, false);
   } else {
-    if (noabort && c->S.wide) PTMI_LAUNCH_BVH_W(false, true, true);
-    else if (noabort) PTMI_LAUNCH_BVH(false, true);
+    if (noabort) PTMI_LAUNCH_BVH(false, true);
     else PTMI_LAUNCH_BVH(false, false);
   }
 #undef PTMI_LAUNCH_BVH
-#undef PTMI_LAUNCH_BVH_W
   HIP_TRY(c, hipGetLastError());
   return PTMI_OK;
 }
@@ -1532,7 +1514,7 @@ void ptmi_destroy(ptmi_ctx* c) {
   drain_spans(c);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (DBuf* b : {&c->d_quad_unit_n, &c->d_spheres, &c->d_sphere_info, &c->d_quads, &c->d_quad_mat, &c->d_tris, &c->d_pretri, &c->d_trinorm, &c->d_meshes, &c->d_xforms,
-                  &c->d_mats, &c->d_pairs, &c->d_wide, &c->d_leaf_table, &c->d_fb_own, &c->d_q0[0], &c->d_q0[1], &c->d_q1[0], &c->d_q1[1], &c->d_q2[0],
+                  &c->d_mats, &c->d_pairs, &c->d_leaf_table, &c->d_fb_own, &c->d_q0[0], &c->d_q0[1], &c->d_q1[0], &c->d_q1[1], &c->d_q2[0],
                   &c->d_q2[1], &c->d_tp[0], &c->d_tp[1], &c->d_hm[0], &c->d_hm[1], &c->d_uv, &c->d_acc, &c->d_pixsum, &c->d_touched, &c->d_ctl, &c->d_totals,
                   &c->d_scratch, &c->d_spill, &c->d_heads, &c->d_fb_gather, &c->d_fb_stage, &c->d_bvh_rows, &c->d_carry[0], &c->d_carry[1]})
     b->release();

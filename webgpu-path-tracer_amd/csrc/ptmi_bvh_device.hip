@@ -180,36 +180,6 @@ struct Dev {  // frees everything on scope exit
   }
 };
 
-// PTMI_BVH_WIDE=1 (round 5's experiment): the four grandchildren of every inner node in one 128-byte record (csrc/ptmi_device.h: inner_step4), made from the pair records
-__global__ void k_pairs_to_wide(const float4* __restrict__ pairs, uint32_t n_inner, float4* __restrict__ wide) {
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n_inner) return;
-  const float4 p0 = pairs[4 * (size_t)r], p1 = pairs[4 * (size_t)r + 1], p2 = pairs[4 * (size_t)r + 2], p3 = pairs[4 * (size_t)r + 3];
-  const uint32_t child_ref[2] = {__float_as_uint(p0.w), __float_as_uint(p1.w)};
-  const float4 child_lo[2] = {p0, p2}, child_hi[2] = {p1, p3};
-  float4 lo[4], hi[4];
-  uint32_t ref[4], axes = (uint32_t)__float_as_int(p2.w) & 3u;
-  for (int c = 0; c < 2; c++) {
-    if (child_ref[c] & 0x80000000u) {  // a leaf: it stands in its own first slot
-      lo[2 * c] = child_lo[c], hi[2 * c] = child_hi[c], ref[2 * c] = child_ref[c];
-      lo[2 * c + 1] = hi[2 * c + 1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f), ref[2 * c + 1] = 0x0fffffffu;  // WIDE_EMPTY
-      axes |= 3u << (2 + 2 * c);
-    } else {
-      const size_t q = 4 * (size_t)child_ref[c];
-      const float4 c0 = pairs[q], c1 = pairs[q + 1], c2 = pairs[q + 2], c3 = pairs[q + 3];
-      lo[2 * c] = c0, hi[2 * c] = c1, ref[2 * c] = __float_as_uint(c0.w);
-      lo[2 * c + 1] = c2, hi[2 * c + 1] = c3, ref[2 * c + 1] = __float_as_uint(c1.w);
-      axes |= ((uint32_t)__float_as_int(c2.w) & 3u) << (2 + 2 * c);
-    }
-  }
-  float4* o = wide + 8 * (size_t)r;
-  const float extra[8] = {__uint_as_float(ref[0]), __uint_as_float(ref[1]), __uint_as_float(ref[2]), __uint_as_float(ref[3]), __uint_as_float(axes), 0.0f, 0.0f, 0.0f};
-  for (int k = 0; k < 4; k++) {
-    o[2 * k] = make_float4(lo[k].x, lo[k].y, lo[k].z, extra[2 * k]);
-    o[2 * k + 1] = make_float4(hi[k].x, hi[k].y, hi[k].z, extra[2 * k + 1]);
-  }
-}
-
 #define TRY(expr)                      \
   do {                                 \
     hipError_t _e = (expr);            \
@@ -872,14 +842,6 @@ extern "C" int ptmi_build_bvh_device(ptmi_ctx* ctx, size_t n_prims, const double
   }
   if (e != hipSuccess) return ptmi_ctx_fail(ctx, e == hipErrorOutOfMemory ? PTMI_ERR_NO_MEMORY : PTMI_ERR_DEVICE, hipGetErrorString(e));
   return PTMI_OK;
-}
-
-int ptmi_bvhdev_make_wide(void* stream_, const float* d_pairs, uint32_t n_inner, float* d_wide) {
-  hipStream_t stream = (hipStream_t)stream_;
-  hipLaunchKernelGGL(k_pairs_to_wide, dim3((n_inner + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const float4*>(d_pairs), n_inner, reinterpret_cast<float4*>(d_wide));
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(stream);
-  return (int)e;
 }
 
 extern "C" int ptmi_build_bvh_sah_device(ptmi_ctx* ctx, size_t n_prims, const double* bmin, const double* bmax, int prim_type, float* nodes_out, int64_t* order_out, size_t* n_nodes_out) {

@@ -261,7 +261,6 @@ struct DevScene {
   const float4* xforms;  // 8 float4 / object: model[4], invModel[4]
   const float4* mats;    // 4 float4 / material
   const float4* pairs;   // 4 float4 / inner node
-  const float4* wide;    // 8 float4 / inner node (PTMI_BVH_WIDE=1, round 5's experiment; null otherwise): the node's four GRANDCHILDREN — see inner_step4
   const int2* leaf_table;
   float4 root_lo, root_hi;  // root box; root_lo.w = root's child ref
   int n_spheres, n_quads, n_tris, n_meshes, n_xforms, n_mats, n_nodes;
@@ -673,47 +672,11 @@ DEV uint32_t inner_step2(float4 f0, float4 f1, float4 f2, float4 f3v, f3 o, f3 i
   return (ptm_min(ct, tbN) > tsN) ? nearRef : N_POP;  // a leaf ref has REF_LEAF set, an inner ref is the pair index
 }
 
-// TWO levels of the reference's tree per fetch (round 5's experiment, PTMI_BVH_WIDE=1; NOABORT trees, uncounted kernels).  The record of inner node P holds the boxes and refs
-// of its four grandchildren {LL.lo, ref LL} {LL.hi, ref LR} {LR.lo, ref RL} {LR.hi, ref RR} {RL.lo, axes} {RL.hi} {RR.lo} {RR.hi}; a child that is a leaf stands in its own first slot
-// and leaves the second one WIDE_EMPTY; axes = axis(P) | axis(L) << 2 | axis(R) << 4, 3 for a leaf child (no swap).  The slots are brought into the order in which the binary walk
-// would reach them — near child's near, near child's far, far child's near, far child's far — the first is tested at once, the others are pushed (far-far first) with their
-// own interval start and flags, exactly the entries the binary walk's pops re-test.  Why the children's own boxes can be skipped: a child's box contains its children's (the
-// builder's min / max are exact), every operation of slab() is monotone, so a grandchild passes only where its parent would have; and closest_so_far only shrinks between
-// the binary walk's test of a far child and of that child's children, so "passes later" implies "the parent passed earlier".  Same triangles in the same order; node visits are
-// NOT the reference's (the counted kernels stay binary), and the stack can hold three entries per two levels.
-constexpr uint32_t WIDE_EMPTY = 0x0fffffffu;
-DEV uint32_t inner_step4(float4 g0, float4 g1, float4 g2, float4 g3, float4 g4, float4 g5, float4 g6, float4 g7, f3 o, f3 inv, float tmin, uint32_t negmask, float ct,
-                         const LaneStack2& stk, int& sp) {
-  float ts0, tb0, ts1, tb1, ts2, tb2, ts3, tb3;
-  slab(g0, g1, o, inv, tmin, ts0, tb0);
-  slab(g2, g3, o, inv, tmin, ts1, tb1);
-  slab(g4, g5, o, inv, tmin, ts2, tb2);
-  slab(g6, g7, o, inv, tmin, ts3, tb3);
-  uint32_t r0 = __float_as_uint(g0.w), r1 = __float_as_uint(g1.w), r2 = __float_as_uint(g2.w), r3 = __float_as_uint(g3.w);
-  const uint32_t axes = __float_as_uint(g4.w);
-  const bool negP = ((negmask >> (axes & 3u)) & 1u) != 0u, negL = ((negmask >> ((axes >> 2) & 3u)) & 1u) != 0u, negR = ((negmask >> ((axes >> 4) & 3u)) & 1u) != 0u;
-  auto swap_if = [](bool c, float& a_ts, float& a_tb, uint32_t& a_r, float& b_ts, float& b_tb, uint32_t& b_r) {
-    const float t0 = c ? b_ts : a_ts, t1 = c ? a_ts : b_ts, u0 = c ? b_tb : a_tb, u1 = c ? a_tb : b_tb;
-    const uint32_t q0 = c ? b_r : a_r, q1 = c ? a_r : b_r;
-    a_ts = t0, b_ts = t1, a_tb = u0, b_tb = u1, a_r = q0, b_r = q1;
-  };
-  swap_if(negL, ts0, tb0, r0, ts1, tb1, r1);
-  swap_if(negR, ts2, tb2, r2, ts3, tb3, r3);
-  swap_if(negP, ts0, tb0, r0, ts2, tb2, r2);
-  swap_if(negP, ts1, tb1, r1, ts3, tb3, r3);
-  auto push = [&](float ts, float tb, uint32_t r) {
-    const bool fB = tb > ts, fA = (fB || (tb != tb)) && r != WIDE_EMPTY;
-    if (fA) {
-      stack2_write(stk, sp, r | REF_A | (fB ? REF_B : 0u), ts);
-      sp++;
-    }
-  };
-  push(ts3, tb3, r3);
-  push(ts2, tb2, r2);
-  push(ts1, tb1, r1);
-  return (r0 != WIDE_EMPTY && ptm_min(ct, tb0) > ts0) ? r0 : N_POP;
-}
-
+// (Round 5 built the walk that takes TWO levels of the reference's tree per fetch — a 128-byte record with a node's four grandchildren in the binary walk's nested near / far
+// order, the first tested at once, the others pushed with their own interval starts; the children's own boxes can be skipped because boxes nest exactly and slab() is monotone.
+// Bit-exact through the parity suite (same triangles in the same order), half the fetches and steps at twice the bytes and ~1.1x the VALU work: k_bvh -2.3 % on configs[2],
+// -4 % on configs[1] / [4], +6 % on configs[3], whatever the LDS stack depth — profiles/r05_bvh_wide_ab.txt, r05_bvh_wide_regions.txt, r05_bvh_wide_lds_stack.txt.  Under the
+// round's bar (-10 % on configs[2]), so it is in the history (commit "Experiment: k_bvh walking two levels ..."), not in the tree.)
 // Pops until an entry passes its re-test against the current closest hit (or the stack is empty): trav_pop_until_pass.
 DEV uint32_t pop_until_pass2(const LaneStack2& stk, int& sp, float ct, Counters& cn, bool count) {
   uint32_t node = N_POP;

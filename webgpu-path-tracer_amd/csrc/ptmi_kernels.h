@@ -171,7 +171,7 @@ __device__ unsigned long long g_tail_tally[3 * kBvhTallies];
 #define BT(k, dep, lanes) ((void)0)
 #endif
 constexpr int kScanGroups = 3, kCandSlots = 64 * (kScanGroups + 1);  // a pass adds at most 64 x kScanGroups candidates to fewer than 64
-template <bool COUNT, bool NOABORT, bool WIDE>
+template <bool COUNT, bool NOABORT>
 DEV void bvh2_body(const DevScene& S, const Paths& P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads, uint32_t n_teams, int stack_size, int lds_entries, int spill_entries,
                    int2* __restrict__ spill, int refill_threshold, int leaf_batch, unsigned long long* __restrict__ totals, uint32_t range_cap, float4 cam, const Carry& cy,
                    int* lds_stack, uint32_t wave_id, uint32_t n_waves  // (stand where blockIdx.x / gridDim.x would: a wave works on its own)
@@ -322,18 +322,10 @@ DEV void bvh2_body(const DevScene& S, const Paths& P, StepCtl* __restrict__ ctl,
         BT(BT_LEAF_TEST, ct, __popcll(pm));
       }
       if (node < N_INNER_LIMIT) {
-        if constexpr (WIDE) {  // two levels per fetch (inner_step4): the experiment of round 5
-          static_assert(NOABORT && !COUNT, "the wide walk keeps neither the reference's stack depth nor its node visits");
-          const float4* rec = S.wide + 8 * (size_t)node;
-          const float4 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3v = rec[3], f4 = rec[4], f5 = rec[5], f6 = rec[6], f7 = rec[7];
-          BT(BT_INNER_FETCH, f0.x + f1.x + f2.x + f3v.x + f4.x + f5.x + f6.x + f7.x, __popcll(__ballot(1)));
-          node = inner_step4(f0, f1, f2, f3v, f4, f5, f6, f7, o, inv, S.tmin, negmask, ct, stk, sp);
-        } else {
-          const float4* rec = S.pairs + 4 * (size_t)node;
-          const float4 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3v = rec[3];
-          BT(BT_INNER_FETCH, f0.x + f1.x + f2.x + f3v.x, __popcll(__ballot(1)));
-          node = inner_step2<COUNT, NOABORT>(f0, f1, f2, f3v, o, inv, S.tmin, negmask, ct, stack_size, stk, sp, cn);
-        }
+        const float4* rec = S.pairs + 4 * (size_t)node;
+        const float4 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3v = rec[3];
+        BT(BT_INNER_FETCH, f0.x + f1.x + f2.x + f3v.x, __popcll(__ballot(1)));
+        node = inner_step2<COUNT, NOABORT>(f0, f1, f2, f3v, o, inv, S.tmin, negmask, ct, stack_size, stk, sp, cn);
         if (node == N_POP) node = pop_until_pass2(stk, sp, ct, cn, COUNT);
       }
       BT(BT_INNER_STEP, __uint_as_float(node), __popcll(im));
@@ -388,14 +380,14 @@ DEV void bvh2_body(const DevScene& S, const Paths& P, StepCtl* __restrict__ ctl,
   if (COUNT) reduce_counters(cn, totals, true);
 }
 
-template <bool COUNT, bool NOABORT, bool WIDE>
+template <bool COUNT, bool NOABORT>
 __global__ __launch_bounds__(64) PTMI_BVH_ATTR void k_bvh2(DevScene S, Paths P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads, uint32_t n_teams, int stack_size,
                                                            int lds_entries, int spill_entries, int2* __restrict__ spill, int refill_threshold, int leaf_batch,
                                                            unsigned long long* __restrict__ totals, uint32_t range_cap, float4 cam,  // cam.w != 0: step 0's queue — every ray starts at cam.xyz
                                                            Carry cy
 ) {
   extern __shared__ int lds_stack[];
-  bvh2_body<COUNT, NOABORT, WIDE>(S, P, ctl, heads, n_teams, stack_size, lds_entries, spill_entries, spill, refill_threshold, leaf_batch, totals, range_cap, cam, cy, lds_stack,
+  bvh2_body<COUNT, NOABORT>(S, P, ctl, heads, n_teams, stack_size, lds_entries, spill_entries, spill, refill_threshold, leaf_batch, totals, range_cap, cam, cy, lds_stack,
                                      blockIdx.x, gridDim.x
   );
 }
