@@ -677,11 +677,12 @@ def worker(args):
         pdist, rank, local = _NoDist, 0, 0
         world = len(devices) if inlib else 1
 
-    def run_workload(name, steps, warmup, spp_arg):
-        wl = make_workload(pkg, name, args)
+    def run_workload(name, steps, warmup, spp_arg, wl_args=None):
+        wl_args = wl_args or args
+        wl = make_workload(pkg, name, wl_args)
         per = spp_arg or SPP[name]
         spp = per * world if args.scaling == "weak" else per
-        ctx = make_context(pkg, wl, devices if inlib else local, args)
+        ctx = make_context(pkg, wl, devices if inlib else local, wl_args)
         reduce_fn = None
         if inlib:
             reduce_fn = ctx.reduce_framebuffer
@@ -872,6 +873,21 @@ def worker(args):
                 wl3["setup"]["bvh_build_js_single_thread"] = js_bvh_build(wl3["native"])
                 wl3["setup"]["obj_parse"] = obj_parse_times(wl3["buffers"]["triangles"].size // 24)
             d3["setup_ms"] = wl3["setup"]
+            # ... and the same scene from the reference's OTHER builder (lib/BVH/bvhNode.js:108-283, which its renderer never calls), built on the GPU: an opt-in
+            # (--bvh sah), so informational here — the configuration's own figure above is on the median tree the reference renders with
+            try:
+                import copy
+
+                a_sah = copy.copy(args)
+                a_sah.bvh = "sah"
+                wls, ctxs, spps, pers, ms = run_workload("c3", 3, 1, 0, a_sah)
+                ds = describe(wls, spps, pers, ms, 3, ms["st"]["rays"], ms["st"]["paths"], ms["dt"], None)
+                ctxs.close()
+                d3["with_sah_tree"] = {"value": ds["value"], "unit": "Mrays/s", "ms_per_step": ds["ms_per_step"], "steps": 3, "warmup": 1, "work_per_ray": ds["roofline"]["work_per_ray"],
+                                       "k_bvh_ms_per_step": ds["roofline"]["kernels"]["k_bvh"]["ms_per_step"], "setup_ms": wls["setup"], "stack_size": wls["stack"],
+                                       "note": "informational: ptmi_build_scene_bvh_sah (binned SAH, byte-identical to the reference's generate_bvh_heirarchy_SAH) instead of the median split"}
+            except Exception as e:  # never let the extra leg cost the line
+                d3["with_sah_tree"] = {"error": str(e)[:200]}
             out["configs"] = [d3]
             # top-level vs_baseline stays null: BASELINE.md publishes no Mrays/s for configs[1]; the dragon ratio belongs to the configs[2] run above
             out["vs_baseline_note"] = "no published number for this metric/config (BASELINE.json `published` is empty); the ratio to the reference's own dragon figure is in configs[0].vs_baseline"

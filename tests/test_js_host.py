@@ -112,6 +112,30 @@ def test_node_host_renders_bit_exact(tmp_path, pkg, oracle):
 
 @pytest.mark.gpu
 @needs_node
+def test_node_host_builds_the_sah_tree_on_the_gpu(tmp_path, pkg, oracle):
+    """--bvh sah: the Node host asks the library for the reference's other builder (buildSceneBVHSAH -> ptmi_build_scene_bvh_sah) over the triangles it has just
+    uploaded; the image is the oracle's on the tree and the triangle order the same build leaves in a Python context."""
+    raw = tmp_path / "fb.f32"
+    b = dict(pkg.scenes.golden_buffers("c2m"))
+    with pkg.Context(0) as ctx:
+        ctx.upload_scene(b)
+        ctx.build_scene_bvh(sah=True)
+        info = ctx.scene_bvh_info()
+        b["bvh"] = ctx.read_scene_buffer("bvh", info["nodes"]).reshape(-1)
+        b["triangles"] = ctx.read_scene_buffer("triangles", b["triangles"].size // 24).reshape(-1)
+    assert info["depth"] < 40 and info["nodes"] <= 2 * (b["triangles"].size // 24) - 1
+    args = [node, "app.mjs", "--golden", os.path.join(ROOT, "tests", "golden", "c2m"), "--width", "160", "--height", "96", "--bounces", "7", "--camera", "oblique", "--raw", str(raw),
+            "--bvh", "sah", "--stack", "40", "--frames", "3"]
+    out = _run(args, cwd=JS, env=dict(os.environ, PTMI_RENDER_AHEAD="0"))
+    st = json.loads(out)["stats"]
+    got = np.fromfile(raw, np.float32).reshape(96, 160, 4)
+    want, ost = oracle.render(b, 160, 96, cornell_view(pkg, "oblique"), 1, 3, max_bounces=7, stack_size=40)
+    assert_same_bits(got, want, "node host, SAH tree built on the GPU")
+    assert st["rays"] == ost["rays"]
+
+
+@pytest.mark.gpu
+@needs_node
 def test_node_host_multi_device_context(tmp_path, pkg, oracle):
     """create([0, 0, 0]): ONE context, three shards (here on one GPU), tiles dealt round-robin, summed on read-back — the image
     and the exact ray count are those of the single-device run.  The reference-shaped Renderer above it is unchanged."""

@@ -182,27 +182,31 @@ def test_two_real_devices_in_one_context(pkg, oracle, monkeypatch):
         assert st["peer_links"] in (0, 2)
 
 
-def test_scene_bvh_built_on_every_device_and_the_collective_on_its_own(pkg, oracle):
-    """ptmi_build_scene_bvh on a multi-device context builds the tree on every device (deterministic: the same bytes everywhere), and
+@pytest.mark.parametrize("sah", [False, True], ids=["median", "sah"])
+def test_scene_bvh_built_on_every_device_and_the_collective_on_its_own(pkg, oracle, sah):
+    """ptmi_build_scene_bvh / ptmi_build_scene_bvh_sah on a multi-device context build the tree on every device (deterministic: the same bytes everywhere), and
     ptmi_reduce_framebuffer — the step's one collective as bench.py times it — leaves the image for ptmi_read_framebuffer: bit-identical to the
     host pipeline on one device."""
     sc = lambda: pkg.scenes.c3_scene(20011)
-    host = sc().buffers(native=pkg.ptmi.NativeHost())
+    host = sc().buffers(native=pkg.ptmi.NativeHost(), sah=sah)
     view = cornell_view(pkg)
-    one, st1, _ = _render(pkg, 0, host, view, 128, 72, 3, max_bounces=5, stack_size=24)
+    params = dict(max_bounces=5, stack_size=40 if sah else 24)
+    one, st1, _ = _render(pkg, 0, host, view, 128, 72, 3, **params)
     with pkg.Context([0, 0, 0]) as ctx:
         ctx.upload_scene(sc().buffers_unbuilt())
-        ctx.build_scene_bvh()
-        ctx.set_params(max_bounces=5, stack_size=24)
+        ctx.build_scene_bvh(sah=sah)
+        ctx.set_params(**params)
         ctx.resize(128, 72)
         ctx.set_counters(True)
         ctx.render(view, 1, 3)
         ctx.reduce_framebuffer()
         got = ctx.read_framebuffer()
         st = ctx.stats()
-        assert np.array_equal(ctx.read_scene_buffer("bvh", 2 * 20011 - 1).reshape(-1).view(np.uint32), np.asarray(host["bvh"], np.float32).view(np.uint32))
+        info = ctx.scene_bvh_info()
+        assert info["nodes"] == host["bvh"].size // 12 and (sah or info["nodes"] == 2 * 20011 - 1)
+        assert np.array_equal(ctx.read_scene_buffer("bvh", info["nodes"]).reshape(-1).view(np.uint32), np.asarray(host["bvh"], np.float32).view(np.uint32))
     assert_same_bits(got, one, "three shards, trees built on the device")
     for k in ("rays", "node_visits", "tri_tests", "quad_tests", "mat_fetches"):
         assert st[k] == st1[k], k
-    want, ost = oracle.render(host, 128, 72, view, 1, 3, max_bounces=5, stack_size=24)
+    want, ost = oracle.render(host, 128, 72, view, 1, 3, **params)
     assert_same_bits(got, want, "vs oracle")

@@ -29,10 +29,19 @@ rows.append("| node visits / triangle tests per ray | " + " | ".join("%.1f / %.2
 rows.append("| ms per step: generate / bvh / shade / tail / accumulate | " + " | ".join(" / ".join(f(k(w, n)["ms_per_step"], 2 if k(w, n)["ms_per_step"] < 100 else 0) for n in ("k_generate", "k_bvh", "k_shade", "k_tail", "k_accumulate")) for w in cols) + " |")
 rows.append("| dominant kernel: bound, `frac` | " + " | ".join("`%s`: %s **%.2f**" % (D[w]["roofline"]["kernel"], {"valu_issue": "VALU issue at 2.4 GHz", "l1_gather": "L1 gather at 2.4 GHz", "hbm": "HBM"}[D[w]["roofline"]["bound"]], D[w]["roofline"]["frac"]) for w in cols) + " |")
 rows.append("| the same kernel: VALU model at the pass clock / all-unclassified-at-4 upper bound / rocprof VALUBusy / lane-weighted at 2.4 GHz | " + " | ".join("%s / %s / %s / %s" % (f(D[w]["roofline"].get("valu_busy_frac_at_pass_clock")), f(D[w]["roofline"].get("valu_busy_frac_upper_bound_at_pass_clock")), f(D[w]["roofline"].get("rocprof_valu_busy")), f(D[w]["roofline"].get("lane_weighted_frac_at_2p4_ghz"))) for w in cols) + " |")
-rows.append("| `k_bvh`: L1 gather / VALU at 2.4 GHz / fabric bytes ÷ 8 TB/s / active lanes / waves parked on memory | " + " | ".join("%s / %s / %s / %s / %s" % (f(k(w, "k_bvh").get("l1_gather_frac")), f(k(w, "k_bvh").get("valu_busy_frac_at_2p4_ghz")), f(k(w, "k_bvh").get("hbm_frac")), f(k(w, "k_bvh").get("active_lane_frac")), f(k(w, "k_bvh").get("wave_wait_frac"))) for w in cols) + " |")
-rows.append("| `k_shade`: VALU at 2.4 GHz / rocprof VALUBusy / HBM / active lanes / waves parked | " + " | ".join("%s / %s / %s / %s / %s" % (f(k(w, "k_shade").get("valu_busy_frac_at_2p4_ghz")), f(k(w, "k_shade").get("rocprof_valu_busy")), f(k(w, "k_shade").get("hbm_frac")), f(k(w, "k_shade").get("active_lane_frac")), f(k(w, "k_shade").get("wave_wait_frac"))) for w in cols) + " |")
-rows.append("| `k_generate`: VALU at 2.4 GHz / at the pass clock / rocprof VALUBusy / HBM | " + " | ".join("%s / %s / %s / %s" % (f(k(w, "k_generate").get("valu_busy_frac_at_2p4_ghz")), f(k(w, "k_generate").get("valu_busy_frac_at_pass_clock")), f(k(w, "k_generate").get("rocprof_valu_busy")), f(k(w, "k_generate").get("hbm_frac"))) for w in cols) + " |")
-rows.append("| one step over the fabric: GB / ÷ 8 TB/s / × the reference megakernel's compulsory bytes | " + " | ".join("%.1f / %s / %.1f×" % (D[w]["roofline"]["step_hbm_bytes"] / 1e9, f(D[w]["roofline"].get("step_hbm_frac")), D[w]["roofline"]["step_hbm_bytes"] / D[w]["roofline"]["compulsory_bytes"]) if D[w]["roofline"].get("step_hbm_bytes") else "—" for w in cols) + " |")
+rows.append("| `k_bvh`: L1 gather / VALU at 2.4 GHz / fabric bytes ÷ 8 TB/s / active lanes / waves parked on memory | " + " | ".join("%s / %s / %s / %s / %s" % (f(k(w, "k_bvh").get("l1_gather_frac")), f(k(w, "k_bvh").get("valu_busy_frac_at_2p4_ghz")), f(k(w, "k_bvh").get("fabric_frac_of_hbm_peak")), f(k(w, "k_bvh").get("active_lane_frac")), f(k(w, "k_bvh").get("wave_wait_frac"))) for w in cols) + " |")
+rows.append("| `k_shade`: VALU at 2.4 GHz / rocprof VALUBusy / fabric bytes ÷ 8 TB/s / active lanes / waves parked | " + " | ".join("%s / %s / %s / %s / %s" % (f(k(w, "k_shade").get("valu_busy_frac_at_2p4_ghz")), f(k(w, "k_shade").get("rocprof_valu_busy")), f(k(w, "k_shade").get("fabric_frac_of_hbm_peak")), f(k(w, "k_shade").get("active_lane_frac")), f(k(w, "k_shade").get("wave_wait_frac"))) for w in cols) + " |")
+rows.append("| `k_generate`: VALU at 2.4 GHz / at the pass clock / rocprof VALUBusy / fabric bytes ÷ 8 TB/s | " + " | ".join("%s / %s / %s / %s" % (f(k(w, "k_generate").get("valu_busy_frac_at_2p4_ghz")), f(k(w, "k_generate").get("valu_busy_frac_at_pass_clock")), f(k(w, "k_generate").get("rocprof_valu_busy")), f(k(w, "k_generate").get("fabric_frac_of_hbm_peak"))) for w in cols) + " |")
+rows.append("| one step over the fabric: GB / ÷ 8 TB/s / × the reference megakernel's compulsory bytes | " + " | ".join("%.1f / %s / %.1f×" % (D[w]["roofline"]["step_fabric_bytes"] / 1e9, f(D[w]["roofline"].get("step_fabric_frac_of_hbm_peak")), D[w]["roofline"]["step_fabric_bytes"] / D[w]["roofline"]["compulsory_bytes"]) if D[w]["roofline"].get("step_fabric_bytes") else "—" for w in cols) + " |")
+S = {}
+for w in cols:
+    p_sah = os.path.join(ROOT, "profiles", "%s_%s_sah_bench.json" % (tag, w))
+    if os.path.exists(p_sah):
+        S[w] = json.load(open(p_sah))
+if S:
+    rows.append("| the same with the opt-in SAH tree (`--bvh sah`, built on the GPU): Mrays/s / node visits per ray / `k_bvh` ms per step / build ms (nodes, depth) | " + " | ".join(
+        "—" if w not in S else "**%.0f** / %.1f / %s / %.0f (%d, %d)" % (S[w]["value"], S[w]["roofline"]["work_per_ray"]["node_visits"], f(S[w]["roofline"]["kernels"]["k_bvh"]["ms_per_step"], 2 if S[w]["roofline"]["kernels"]["k_bvh"]["ms_per_step"] < 100 else 0),
+                                                        S[w]["setup_ms"]["build_scene_bvh_sah_device_ms"], S[w]["setup_ms"]["sah_tree"]["nodes"], S[w]["setup_ms"]["sah_tree"]["depth"]) for w in cols) + " |")
 rows.append("| CPU oracle, 16 threads / 1 thread (Mrays/s) | " + " | ".join("%.1f / %.1f" % (D[w]["cpu_baseline"]["value"], D[w]["cpu_baseline"]["single_thread"]["value"]) for w in cols) + " |")
 rows.append("| vs. 33.5 Mpaths/s (`benchmarks.txt:18-20`): paths / rays | " + " | ".join("%.0f× / %.0f×" % (D[w]["config"]["mpaths_per_s"] / 33.5, D[w]["value"] / 33.5) for w in cols) + " |")
 table = "\n".join("  " + r for r in rows)

@@ -17,6 +17,10 @@ echo "bench.py --steps 20 --warmup 5: wall ${SECONDS} s" | tee $R/bench_c2_wall.
 timeout -k 10 600 python bench.py --workload c3 --steps 2 --cpu-seconds 10 --extra-configs off > $R/bench_c3.json 2> $R/bench_c3.err || exit 1
 timeout -k 10 600 python bench.py --workload c4 --steps 1 --cpu-seconds 10 --pmc-timeout 400 > $R/bench_c4.json 2> $R/bench_c4.err || exit 1
 timeout -k 10 600 python bench.py --workload c5 --width 3840 --height 2160 --spp 128 --steps 1 --cpu-seconds 10 --pmc-timeout 400 > $R/bench_c5.json 2> $R/bench_c5.err || exit 1
+# the opt-in SAH tree (lib/BVH/bvhNode.js:108-283, built on the GPU: ptmi_build_scene_bvh_sah) on the same box, with its own counter passes
+timeout -k 10 600 python bench.py --workload c3 --bvh sah --steps 2 --cpu-seconds 0 --extra-configs off > $R/bench_c3_sah.json 2> $R/bench_c3_sah.err || exit 1
+timeout -k 10 600 python bench.py --workload c4 --bvh sah --steps 1 --cpu-seconds 0 --pmc-timeout 400 > $R/bench_c4_sah.json 2> $R/bench_c4_sah.err || exit 1
+timeout -k 10 600 python bench.py --workload c5 --bvh sah --width 3840 --height 2160 --spp 128 --steps 1 --cpu-seconds 0 --pmc-timeout 400 > $R/bench_c5_sah.json 2> $R/bench_c5_sah.err || exit 1
 # rocprofv3 kernel stats of the bench command itself (its own --pmc child passes off: one profiler at a time)
 for w in c2 c3 c4 c5; do
   rm -rf /tmp/ks_$w
@@ -31,7 +35,7 @@ bash tools/valu_busy_calib.sh > $R/valu_busy_calib.txt 2>&1 && cp gpurun_out/val
 # the gather path's ceiling (k_bvh's roofline) and the sweeps that show k_bvh sits on it
 [ -x tools/gather_probe ] && timeout -k 10 300 tools/gather_probe > $R/gather_probe.json 2> $R/gather_probe.err
 bash tools/sweep.sh size > /dev/null 2>&1; cp gpurun_out/sweep/size_sweep.txt $R/ 2>/dev/null
-timeout -k 10 400 python tools/shard_sim.py c2 c3 > $R/shard_sim.txt 2>&1 && cp gpurun_out/shard_sim.json $R/
+timeout -k 10 900 python tools/shard_sim.py c2 c3 c4 c5 > $R/shard_sim.txt 2>&1 && cp gpurun_out/shard_sim.json $R/
 timeout -k 10 400 python tools/obj_parse_bench.py > $R/obj_parse.json 2> $R/obj_parse.err
 if [ -f webgpu-path-tracer_amd/variants/libptmi_lanes.so ]; then
   for w in c2 c3 c5; do timeout -k 10 200 python tools/shade_lanes.py run $w > $R/shade_lanes_$w.txt 2>&1 && cp gpurun_out/shade_lanes_$w.json $R/; done

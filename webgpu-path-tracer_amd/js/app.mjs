@@ -1,6 +1,8 @@
 // app.mjs — headless Node application on the shipped host code (no reference checkout needed):
 //   node app.mjs --golden <dir>/c2 --width 160 --height 90 --frames 4 --bounces 8 --camera cornell --raw out.f32 [--out out.ppm]
 //   node app.mjs --obj model.obj --scale 0.6 --translate 0,-0.4,0 ...       (Cornell box + one OBJ mesh)
+//   ... --bvh device | sah : build the tree on the GPU over the uploaded triangles instead of using the uploaded one — Scene.create_bvh()'s median split
+//   (ptmi_build_scene_bvh), or the reference's other, never-called builder (lib/BVH/bvhNode.js:108-283; ptmi_build_scene_bvh_sah; give --stack above its depth)
 // Loads a scene (golden typed arrays or built with lib/scene.mjs), drives Renderer -> WebGPU shim -> ptmi.node.
 import fs from 'fs';
 import { Ptmi, loadNative } from './ptmi.mjs';
@@ -37,6 +39,8 @@ async function main() {
   const renderer = await Renderer.create(device);
   const module = renderer.createShaderModule({ MAX_BOUNCES: Number(opt('bounces', 8)), IMPORTANCE_SAMPLING: args.includes('--is'), STACK_SIZE: Number(opt('stack', 20)) });
   await renderer.initBuffers(null, camera, W, H, buffers);
+  if (opt('bvh', null) === 'sah') backend.buildSceneBVHSAH();
+  else if (opt('bvh', null) === 'device') backend.buildSceneBVH();
   renderer.createComputePipeline(module);
   renderer.createRenderPipeline(module);
   renderer.setRenderParameters({}, camera, W, H);
