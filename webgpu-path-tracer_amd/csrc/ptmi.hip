@@ -1679,6 +1679,7 @@ static int build_scene_bvh_one(ptmi_ctx* c, bool sah) {
   if (r || bad != 0xffffffffu) {
     rows.release();
     tris2.release();
+    if (r == (int)hipErrorNotSupported) return fail(c, PTMI_ERR_UNSUPPORTED, "ptmi_build_scene_bvh_sah: the SAH tree of these triangles is deeper than 512 levels (no STACK_SIZE <= 64 can traverse it)");
     if (r) return fail(c, r == (int)hipErrorOutOfMemory ? PTMI_ERR_NO_MEMORY : PTMI_ERR_DEVICE, std::string("ptmi_build_scene_bvh: ") + hipGetErrorString((hipError_t)r));
     char msg[160];
     snprintf(msg, sizeof msg, "ptmi_build_scene_bvh: triangle %u: mesh_id / the mesh's global_id out of range (meshes %d, transforms %d)", bad, n_mesh, n_xf);
