@@ -261,8 +261,8 @@ int ptmi_build_bvh(size_t n_prims, const double* bmin, const double* bmax, int p
 /* Opt-in binned-SAH build: the reference's second builder, BVH.generate_bvh_heirarchy_SAH
  * (lib/BVH/bvhNode.js:108-283; 8 bins, leaves of any size), which the reference itself never calls —
  * its renderer uses the median split above.  Same inputs; nodes_out must hold (2n-1) x 12 floats,
- * *n_nodes_out receives the number of rows written.  Host threads: PTMI_BUILD_THREADS (default: all)
- * applies to ptmi_build_bvh only. */
+ * *n_nodes_out receives the number of rows written.  Host threads: PTMI_BUILD_THREADS (default: all, at most 32);
+ * the same bytes for any number of them. */
 int ptmi_build_bvh_sah(size_t n_prims, const double* bmin, const double* bmax, int prim_type, float* nodes_out,
                        int64_t* order_out, size_t* n_nodes_out);
 

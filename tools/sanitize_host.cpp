@@ -30,8 +30,15 @@ int main() {
       printf("thread-count dependence at n=%zu\n", n);
       return 2;
     }
-    size_t rows = 0;
-    if (ptmi_build_bvh_sah(n, lo.data(), hi.data(), 2, s.data(), os.data(), &rows) || rows == 0 || rows > 2 * n - 1) return 3;
+    size_t rows = 0, rows1 = 0;
+    std::vector<float> s1(a.size());
+    std::vector<int64_t> os1(n);
+    if (ptmi_build_bvh_sah(n, lo.data(), hi.data(), 2, s.data(), os.data(), &rows) || rows == 0 || rows > 2 * n - 1) return 3;  // 8 threads: subtrees fork where a thread is free
+    setenv("PTMI_BUILD_THREADS", "1", 1);
+    if (ptmi_build_bvh_sah(n, lo.data(), hi.data(), 2, s1.data(), os1.data(), &rows1) || rows1 != rows || memcmp(s.data(), s1.data(), rows * 48) || os != os1) {
+      printf("SAH: thread-count dependence at n=%zu\n", n);
+      return 5;
+    }
   }
   std::string obj = "# c\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1/1/1 2/1/1 3/1/1\nf 1//1 9//1 3//7\nv 1e3 0x10 -Infinity\nf 4 4 4\nv\n";
   float *v = nullptr, *nn = nullptr;

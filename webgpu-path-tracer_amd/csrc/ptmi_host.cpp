@@ -6,6 +6,7 @@
 // to f32 on the final store like `new Float32Array(...)` (lib/scene.js:304).  Output is byte-identical
 // to the reference's for the same boxes (tests/test_host_buffers.py checks it against goldens).
 #include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <cmath>
 #include <cstdint>
@@ -248,13 +249,15 @@ struct SahBuilder {
     }
   }
 
-  // generate_bvh_heirarchy_SAH (bvhNode.js:108-202); an explicit stack as there: SAH trees can be very deep
-  void build(int64_t n) {
-    nodes.clear();
-    nodes.emplace_back();
-    nodes[0].start = 0;
-    nodes[0].end = n - 1;
-    std::vector<int64_t> todo{0};
+  // generate_bvh_heirarchy_SAH (bvhNode.js:108-202); an explicit stack as there: SAH trees can be very deep.  Subtrees over disjoint ranges of `order` are
+  // independent, so the upper levels hand their right halves to threads of their own (round 5: 4.4 s -> a few hundred ms at 871 k boxes): node records come out of
+  // a pre-sized array through an atomic counter — their numbers depend on the timing, the tree and its pre-order flattening do not.
+  std::atomic<int64_t> n_alloc{1};
+  std::atomic<int> running{1};  // threads at work on subtrees (SAH splits are lopsided: a fixed fork depth leaves most threads idle, so a subtree forks whenever one is free)
+  int max_threads = 1;
+  void build_subtree(int64_t root) {
+    std::vector<int64_t> todo{root};
+    std::vector<std::future<void>> kids;
     while (!todo.empty()) {
       const int64_t id = todo.back();
       todo.pop_back();
@@ -271,21 +274,47 @@ struct SahBuilder {
         continue;
       }
       const double* keys = bmin;
-      std::stable_sort(order + start, order + end + 1, [keys, axis](int64_t a, int64_t b) { return keys[3 * a + axis] < keys[3 * b + axis]; });
+      // (the big ranges near the root also sort on the threads that have nothing else to do yet)
+      int sort_forks = 0;
+      for (int spare = max_threads - running.load(); end - start >= 65536 && (1 << sort_forks) <= spare; sort_forks++) {
+      }
+      par_stable_sort(order + start, order + end + 1, [keys, axis](int64_t a, int64_t b) { return keys[3 * a + axis] < keys[3 * b + axis]; }, sort_forks);
       int64_t split = start;
       while (split < end - 1) {
         if (centroid(order[split], axis) <= split_pos) split++;
         else break;
       }
-      const int64_t l = (int64_t)nodes.size(), r = l + 1;
-      nodes.emplace_back();
-      nodes.emplace_back();
+      const int64_t l = n_alloc.fetch_add(2), r = l + 1;
       nodes[l].start = start, nodes[l].end = split;
       nodes[r].start = split + 1, nodes[r].end = end;
       nodes[id].left = l, nodes[id].right = r, nodes[id].axis = axis;
-      todo.push_back(r);
+      bool forked = false;
+      if (end - split >= 8192 && split - start >= 8192 && running.load() < max_threads) {
+        running.fetch_add(1);
+        try {
+          kids.push_back(std::async(std::launch::async, [this, r] {
+            build_subtree(r);
+            running.fetch_sub(1);
+          }));
+          forked = true;
+        } catch (...) {  // no thread to be had: the right half is built here too
+          running.fetch_sub(1);
+        }
+      }
+      if (!forked) todo.push_back(r);
       todo.push_back(l);
     }
+    for (auto& k : kids) k.get();
+  }
+  void build(int64_t n, int threads) {
+    max_threads = threads;
+    running = 1;
+    nodes.assign((size_t)(2 * n - 1), SahNode());  // every leaf holds at least one primitive: at most 2n - 1 nodes
+    n_alloc = 1;
+    nodes[0].start = 0;
+    nodes[0].end = n - 1;
+    build_subtree(0);
+    nodes.resize((size_t)n_alloc.load());
   }
 };
 
@@ -302,7 +331,10 @@ extern "C" int ptmi_build_bvh_sah(size_t n_prims, const double* bmin, const doub
     SahBuilder b;
     b.bmin = bmin, b.bmax = bmax, b.order = order_out;
     for (size_t i = 0; i < n_prims; i++) order_out[i] = (int64_t)i;
-    b.build((int64_t)n_prims);
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char* e = getenv("PTMI_BUILD_THREADS")) hw = (unsigned)std::max(1, atoi(e));
+    hw = std::min(hw ? hw : 1u, 32u);
+    b.build((int64_t)n_prims, (int)hw);
     // flattenBVH (bvhBuilder.js:37-54): pre-order ids; populate_links (bvhNode.js:76-93): the skip link
     const size_t nn = b.nodes.size();
     std::vector<int64_t> flat_id(nn, -1);
