@@ -125,6 +125,7 @@ struct Tuning {
   int refill = kRefillThreshold, leaf_batch = kLeafBatch, bvh_range = (int)kBvhRange;  // PTMI_REFILL, PTMI_LEAF_BATCH, PTMI_BVH_RANGE
   int tail_waves_per_cu = 0;   // PTMI_TAIL_WAVES_PER_CU (0 = 16, or 24 for the 6-wave build)
   bool tail6 = true;           // PTMI_TAIL6=0: never the 80-VGPR build of k_tail
+  int tail_park = 16;          // PTMI_TAIL_PARK: k_tail's tree walk parks its last lanes once fewer than this many are left in it (trees of >= 12 levels only; 0 = never)
   int bvh_carry = 32;          // PTMI_BVH_CARRY: iterations a k_bvh wave goes on after the queue is exhausted before it carries its unfinished rays into the next
                                // step's queue (Carry, ptmi_device.h); 0 = never (every launch traces its longest ray to the end)
   int bvh_carry_slots = 1 << 18;  // PTMI_BVH_CARRY_SLOTS: the queues' carry prefix
@@ -740,6 +741,7 @@ void load_tuning(ptmi_ctx* c) {
   t.bvh_range = std::max(64, std::min(1 << 16, env_int("PTMI_BVH_RANGE", t.bvh_range))) & ~63;
   t.tail_waves_per_cu = std::max(0, std::min(32, env_int("PTMI_TAIL_WAVES_PER_CU", t.tail_waves_per_cu)));
   t.tail6 = env_int("PTMI_TAIL6", 1) != 0;
+  t.tail_park = std::max(0, std::min(63, env_int("PTMI_TAIL_PARK", t.tail_park)));
   t.bvh_carry = std::max(0, env_int("PTMI_BVH_CARRY", t.bvh_carry));
   t.bvh_carry_slots = std::max(64, std::min(1 << 22, env_int("PTMI_BVH_CARRY_SLOTS", t.bvh_carry_slots)));
   t.bvh_carry_last = std::max(0, env_int("PTMI_BVH_CARRY_LAST", t.bvh_carry_last));
@@ -809,8 +811,12 @@ int launch_intersect(ptmi_ctx* c, const Paths& P, StepCtl* ctl, uint32_t max_ite
 }
 
 // k_tail in front of a step: traces the step's queue to the end if it is short (PTMI_TAIL_LIMIT slots, 0 = never launched), else returns at once.
-int launch_tail(ptmi_ctx* c, const RenderConst& rc, const Paths& P, StepCtl* ctl, int first, uint32_t limit, const Carry& cy) {
-  const int sa = stack_alloc_for(c);
+int launch_tail(ptmi_ctx* c, const RenderConst& rc, const Paths& P, StepCtl* ctl, int first, uint32_t limit, const Carry& cy_in) {
+  // On trees of 12 levels and more a walk stops once fewer than tun.tail_park lanes are left in it while other lanes have work; the stragglers' state waits in three entries
+  // on top of their stacks (tail_body).  Shallow trees never park: their walks are short, and a parked ray's path waits for the next walk (round 4 measured both).
+  Carry cy = cy_in;
+  cy.park_below = (c->S.n_nodes > 0 && c->bvh_depth >= 12) ? c->tun.tail_park : 0;
+  const int sa = stack_alloc_for(c) + (cy.park_below > 0 ? 3 : 0);
   const int le = std::min(sa, c->tun.lds_stack);
   const int se = sa - le;
   const size_t lds = (size_t)le * 2 * 64 * sizeof(int);
@@ -960,10 +966,12 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   const int tail_env = c->tun.tail_limit;
   // Where k_tail's weak spot — the tree walk, as long as the wave's longest ray — is short, it stays ahead of the per-bounce kernels far longer (round 5,
   // profiles/r05_tail_first_sweep*.txt): on configs[1]'s 11-level tree it wins up to ~24 Mi paths per batch (4 Mi paths: 0.94 ms against 1.54; 16.6 Mi — one rank of eight at
-  // fixed total spp, or an 8-frame render-ahead batch — 2.87 against 3.26), on the 871 k-triangle tree only up to ~4 Mi, inside the 262 k-triangle room never.  So the 80-VGPR
-  // build's scenes with a tree under 12 levels hand whole batches of up to 24 Mi slots to it, and their later steps' queues from 2 Mi down.
-  const bool shallow = c->S.n_nodes > 0 && c->bvh_depth < 12 && !p.importance_sampling && rc.num_samples == 1 && c->S.n_spheres == 0 && c->tun.tail6;
-  const uint32_t tail_limit_first = (uint32_t)(tail_env >= 0 ? tail_env : shallow ? kTailLimitFirstShallow : kTailLimitFirst),
+  // fixed total spp, or an 8-frame render-ahead batch — 2.87 against 3.26).  On deep trees, since its walks park their stragglers (launch_tail), up to ~16 Mi paths on the
+  // 871 k-triangle scene (4 Mi: 3.5 ms against 6.5; 8 Mi: 4.9 against 6.4) but only ~4 Mi inside the 262 k-triangle room (8 Mi: 22.1 against 20.8): 6 Mi.  The builds with
+  // importance sampling, several samples or spheres (100-130 VGPRs, 4 waves per SIMD) keep 2 Mi.  Later steps' queues: from 2 Mi down on shallow trees, 1 Mi otherwise.
+  const bool six = !p.importance_sampling && rc.num_samples == 1 && c->S.n_spheres == 0 && c->tun.tail6;
+  const bool shallow = six && c->S.n_nodes > 0 && c->bvh_depth < 12, deep = six && c->S.n_nodes > 0 && c->bvh_depth >= 12 && c->tun.tail_park > 0;
+  const uint32_t tail_limit_first = (uint32_t)(tail_env >= 0 ? tail_env : shallow ? kTailLimitFirstShallow : deep ? kTailLimitFirstDeep : kTailLimitFirst),
                  tail_limit_later = (uint32_t)(tail_env >= 0 ? tail_env : shallow ? kTailLimitLaterShallow : kTailLimitLater);
 
   ScopedSpan whole(c, T_RENDER);
@@ -1679,7 +1687,7 @@ static int build_scene_bvh_one(ptmi_ctx* c, bool sah) {
   if (r || bad != 0xffffffffu) {
     rows.release();
     tris2.release();
-    if (r == (int)hipErrorNotSupported) return fail(c, PTMI_ERR_UNSUPPORTED, "ptmi_build_scene_bvh_sah: the SAH tree of these triangles is deeper than 512 levels (no STACK_SIZE <= 64 can traverse it)");
+    if (r == (int)hipErrorNotSupported) return fail(c, PTMI_ERR_UNSUPPORTED, "ptmi_build_scene_bvh_sah: the SAH tree of these triangles is deeper than 4096 levels (no STACK_SIZE <= 64 can traverse it)");
     if (r) return fail(c, r == (int)hipErrorOutOfMemory ? PTMI_ERR_NO_MEMORY : PTMI_ERR_DEVICE, std::string("ptmi_build_scene_bvh: ") + hipGetErrorString((hipError_t)r));
     char msg[160];
     snprintf(msg, sizeof msg, "ptmi_build_scene_bvh: triangle %u: mesh_id / the mesh's global_id out of range (meshes %d, transforms %d)", bad, n_mesh, n_xf);

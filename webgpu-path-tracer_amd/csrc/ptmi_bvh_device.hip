@@ -359,7 +359,7 @@ __host__ __device__ inline double sah_dec(unsigned long long u) {
   memcpy(&x, &u, 8);
   return x;
 }
-constexpr int kSahBins = 8, kSahMaxLevels = 512;
+constexpr int kSahBins = 8, kSahMaxLevels = 4096;
 struct alignas(64) SahBin {
   unsigned long long lo[3], hi[3];  // sah_enc'ed box of the primitives whose centroid falls into the bin
   uint32_t count;
@@ -650,9 +650,9 @@ hipError_t build_levels_sah(hipStream_t stream, Dev& d, uint32_t n, const double
   uint32_t m = 1, total = 0;
   int cur = 0, ocur = 0;
   while (m > 0) {
-    // A level costs a pass over all n primitives whatever it splits, and binned SAH can peel one primitive per level off an adversarial cloud (depth ~ n: hours for a
-    // million boxes — the host builder and the reference's own JavaScript are O(n * depth) too).  No traversal can use such a tree (STACK_SIZE <= 64; these meshes: 27-31
-    // levels), so the build gives up long before it becomes a hang.
+    // A level costs a pass over all n primitives whatever it splits.  Binned SAH shrinks a node's centroid range by at least 1/8 per split along the chosen axis, so doubles
+    // bound the depth by a few thousand levels (clusters of nearly coincident centroids — tests/test_parity_gpu.py has one — reach several hundred; real meshes 27-31).
+    // The cap only keeps a build from turning into a hang should that reasoning miss a case; no traversal could use such a tree anyway (STACK_SIZE <= 64).
     if (levels.size() >= (size_t)kSahMaxLevels) return hipErrorNotSupported;
     levels.emplace_back(total, m);
     {
@@ -865,7 +865,7 @@ extern "C" int ptmi_build_bvh_sah_device(ptmi_ctx* ctx, size_t n_prims, const do
   } catch (...) {
     return ptmi_ctx_fail(ctx, PTMI_ERR_NO_MEMORY, "ptmi_build_bvh_sah_device: host allocation failed");
   }
-  if (e == hipErrorNotSupported) return ptmi_ctx_fail(ctx, PTMI_ERR_UNSUPPORTED, "ptmi_build_bvh_sah_device: the SAH tree of these boxes is deeper than 512 levels (no STACK_SIZE <= 64 can traverse it)");
+  if (e == hipErrorNotSupported) return ptmi_ctx_fail(ctx, PTMI_ERR_UNSUPPORTED, "ptmi_build_bvh_sah_device: the SAH tree of these boxes is deeper than 4096 levels (no STACK_SIZE <= 64 can traverse it)");
   if (e != hipSuccess) return ptmi_ctx_fail(ctx, e == hipErrorOutOfMemory ? PTMI_ERR_NO_MEMORY : PTMI_ERR_DEVICE, hipGetErrorString(e));
   return PTMI_OK;
 }

@@ -327,6 +327,8 @@ struct Carry {
   int rec_words;       // words per pool record: 8 (state word, sp, closest t, u, v, prim, material word, -) + 2 per stack entry
   uint32_t* pool_in;   // records of this queue's carried rays, by slot
   uint32_t* pool_out;  // records of the next queue's
+  int park_below;      // k_tail only (round 5): its tree walk stops once fewer than this many lanes are still in it while other lanes have work, and the stragglers resume
+                       // in the next walk (0 = a walk always runs to its longest ray's end) — tail_body
 };
 DEV bool dead_slot(uint32_t slot, uint32_t n_carried, uint32_t resv) { return slot >= n_carried && slot < resv; }
 // The hitScene tally of the batch being traced (slots that held a path, summed over its steps) is spread over kTallyLines counters on

@@ -600,6 +600,7 @@ DEV bool shade_one(const DevScene& S, const RenderConst& rc, const Paths& P, con
 constexpr uint32_t kRegionDiv = 16;  // a block's share of the queue is claimed in this many regions (x4: every wave claims its own)
 constexpr int kTailLimitFirst = 2 << 20, kTailLimitLater = 1 << 20;  // k_tail takes a queue over when it is at most this long (slots): at step 0 (a lone 1080p frame fits) / later (round 4: 512 Ki -> 1 Mi since its tree walk waits for 24 lanes — 8-frame batches of configs[1] +5 %, 64-frame ones and configs[2] unchanged: profiles/r04_tail_limit_ab.txt)
 constexpr int kTailLimitFirstShallow = 24 << 20, kTailLimitLaterShallow = 2 << 20;  // ... on trees under 12 levels (render_batch)
+constexpr int kTailLimitFirstDeep = 6 << 20;  // ... on deeper ones, whose walks park their stragglers (render_batch)
 constexpr int kTailRefill = 16;  // k_tail: idle lanes before a wave takes new paths
 constexpr bool kMissShortcut = true;  // definite misses are settled in k_shade's flush phase
 constexpr int kSChunk = 512;  // slots a k_shade block sorts, shades and compacts at a time
@@ -1089,6 +1090,7 @@ DEV void tail_body(const DevScene& S, const RenderConst& rc, const Paths& P, Ste
   st.hitmat = HITMAT_HOLE, st.slot = 0;
   bool alive = false;
   bool resume = false;  // the lane's path was taken from the carry prefix: its hitScene part 2 goes on from the pool's record (first iteration only)
+  int park_sp = -1;     // >= 0: the lane's walk was interrupted (Carry::park_below); its state waits in three entries on top of its own stack, from this one on
   float2 uv = make_float2(0.0f, 0.0f);  // barycentrics of the lane's triangle hit (the queue comes from k_generate / k_shade: none in it yet)
   uint32_t gnext = blockIdx.x, gbase = 0, pos = 64;  // next group to open; the open group's first slot and how many of its slots are taken
 #ifdef PTMI_LANE_TALLY
@@ -1156,8 +1158,26 @@ DEV void tail_body(const DevScene& S, const RenderConst& rc, const Paths& P, Ste
           for (int e = 0; e < sp; e++) stack2_write(stk, e, rec[8 + 2 * e], __uint_as_float(rec[9 + 2 * e]));
         }
         resume = false;
+        if (flagged && park_sp >= 0) {  // interrupted in an earlier walk: on from where it stopped
+          uint32_t w0;
+          float w1;
+          sp = park_sp;
+          stack2_read(stk, sp, w0, w1);
+          node = w0, ct = w1;
+          stack2_read(stk, sp + 1, w0, w1);
+          hit.u = __uint_as_float(w0), hit.v = w1;
+          stack2_read(stk, sp + 2, w0, w1);
+          hit.prim = w0, hit.mat = __float_as_uint(w1);
+          park_sp = -1;
+        }
 #pragma unroll 1
-        while (__ballot(node != N_DONE) != 0ull) {
+        for (;;) {
+          const uint64_t wm = __ballot(node != N_DONE);
+          if (wm == 0ull) break;
+          // A walk lasts as long as its longest ray, and on a deep tree most of it runs a handful of lanes wide (871 k triangles: 7 of 64 on average, two thirds of a lone
+          // frame's wave-cycles).  Once fewer than park_below lanes are left in it and another lane has something to do — a path to shade, or the queue a path to
+          // take — the stragglers are parked and join the next walk.
+          if (cy.park_below > 0 && (int)__popcll(wm) < cy.park_below && (more_to_take || __ballot(alive && !(flagged && node != N_DONE)) != 0ull)) break;
           if ((int)node < 0) {
             const int2 lc = (node & REF_MULTI) ? S.leaf_table[node & REF_IDX] : make_int2((int)(node & REF_IDX), 1);
             for (int j = 0; j < lc.y; j++) {
@@ -1177,12 +1197,19 @@ DEV void tail_body(const DevScene& S, const RenderConst& rc, const Paths& P, Ste
           }
           BT(TB_WALK_STEP, __uint_as_float(node), __popcll(__ballot(node != N_DONE)));
         }
-        if (hit.prim != 0u) {  // a triangle beat what part 1 had found
-          st.tp = make_float2(ct, __uint_as_float(hit.prim));
-          uv = make_float2(hit.u, hit.v);
-          st.hitmat = hit.mat;
+        if (flagged && node != N_DONE) {  // parked: node / closest hit so far on top of the lane's own stack (its entries below stay where they are); HITMAT_BVH stays set
+          stack2_write(stk, sp, node, ct);
+          stack2_write(stk, sp + 1, __float_as_uint(hit.u), hit.v);
+          stack2_write(stk, sp + 2, hit.prim, __uint_as_float(hit.mat));
+          park_sp = sp;
+        } else {
+          if (hit.prim != 0u) {  // a triangle beat what part 1 had found
+            st.tp = make_float2(ct, __uint_as_float(hit.prim));
+            uv = make_float2(hit.u, hit.v);
+            st.hitmat = hit.mat;
+          }
+          st.hitmat &= ~HITMAT_BVH;  // (the walk is done: the lane shades now)
         }
-        st.hitmat &= ~HITMAT_BVH;  // (the walk is done: the lane shades now)
       }
       // ---- ray_color's loop body (traceRay.wgsl:10-80), for the lanes that do not wait for the tree ----
       const bool go = alive && (st.hitmat & HITMAT_BVH) == 0u;
