@@ -815,7 +815,7 @@ int launch_tail(ptmi_ctx* c, const RenderConst& rc, const Paths& P, StepCtl* ctl
   // On trees of 12 levels and more a walk stops once fewer than tun.tail_park lanes are left in it while other lanes have work; the stragglers' state waits in three entries
   // on top of their stacks (tail_body).  Shallow trees never park: their walks are short, and a parked ray's path waits for the next walk (round 4 measured both).
   Carry cy = cy_in;
-  cy.park_below = (c->S.n_nodes > 0 && c->bvh_depth >= 12) ? c->tun.tail_park : 0;
+  cy.park_below = (c->S.n_nodes > 0 && c->bvh_depth >= 12) ? c->tun.tail_park : 0;  // (shallower: configs[1] -4 % at 8 lanes, +4 % at 16, the default scene +37 %: profiles/r05_tail_park_shallow.txt)
   const int sa = stack_alloc_for(c) + (cy.park_below > 0 ? 3 : 0);
   const int le = std::min(sa, c->tun.lds_stack);
   const int se = sa - le;
