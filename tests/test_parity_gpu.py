@@ -923,6 +923,43 @@ def test_rays_carried_into_the_next_step_change_nothing(pkg, oracle, monkeypatch
                 assert st[k] == ost[k], (name, k, st[k], ost[k])
 
 
+@pytest.mark.parametrize("park", [0, 4, 16, 63])
+def test_tail_walk_parking_changes_nothing(pkg, oracle, monkeypatch, pipeline, park):
+    """k_tail on trees of 12 levels and more (round 5): a tree walk stops once fewer than PTMI_TAIL_PARK lanes are left in it while another lane has work, the
+    stragglers' state (node, closest hit so far) waits in three entries on top of their own stacks — in LDS, or in the spill area where the stack is deeper than
+    its LDS part — and they join the next walk.  Same triangles in the same order whenever a walk is cut: the framebuffer bits and the exact counters of the
+    oracle for never (0), almost never (4), the default (16) and always-while-anybody-else-has-work (63); with the Q7 abort live (stack_size 6 on a 15-level
+    tree: the frame sits on top of a full-height stack) and with rays that k_bvh carried over into k_tail's hands (the mixed pipeline)."""
+    if pipeline == "wavefront":
+        pytest.skip("PTMI_TAIL_LIMIT=0: k_tail is never launched")
+    monkeypatch.setenv("PTMI_TAIL_PARK", str(park))
+    for k, v in (("PTMI_BVH_CARRY", 2), ("PTMI_BVH_CARRY_SLOTS", 4096), ("PTMI_BVH_CARRY_MIN_PATHS", 0), ("PTMI_BVH_CARRY_MIN_DEPTH", 0)):
+        monkeypatch.setenv(k, str(v))
+    if pipeline == "mixed":
+        monkeypatch.setenv("PTMI_TAIL_LIMIT", "20000")  # the later bounces' queues (and the carried rays with them) go to k_tail
+    b = pkg.scenes.c3_scene(30011).buffers(native=pkg.ptmi.NativeHost())
+    view = cornell_view(pkg)
+    with pkg.Context(0) as ctx:
+        assert ctx.upload_scene(b) is None
+        for params in (dict(max_bounces=8, stack_size=24), dict(max_bounces=6, stack_size=6), dict(max_bounces=5, stack_size=24, importance_sampling=1)):
+            ctx.set_params(**params)
+            ctx.resize(224, 126)
+            ctx.reset_stats()
+            ctx.set_counters(True)
+            ctx.render(view, 1, 3)
+            got = ctx.read_framebuffer()
+            st = ctx.stats()
+            ctx.set_counters(False)
+            ctx.clear()
+            ctx.render(view, 1, 3)
+            got_uncounted = ctx.read_framebuffer()
+            want, ost = oracle.render(b, 224, 126, view, 1, 3, **params)
+            assert_same_bits(got, want, "parking below %d lanes, %r" % (park, params))
+            assert_same_bits(got_uncounted, want, "parking below %d lanes, %r, uncounted kernels" % (park, params))
+            for k in ("rays", "paths", "node_visits", "tri_tests", "quad_tests", "mat_fetches"):
+                assert st[k] == ost[k], (park, params, k, st[k], ost[k])
+
+
 def _two_mesh_scene(pkg):
     """Deterministic: the Cornell walls + two small procedural meshes with different (rotated, non-uniformly scaled, translated) transforms."""
     import math
