@@ -47,10 +47,11 @@ def run(workload="c2", spp=0):
     buf = (ctypes.c_uint64 * (2 * len(POINTS)))()
     ctx.clear(); ctx.render(wl["view"], 1, spp); ctx.synchronize()
     assert lib.ptmi_lane_tally(ctx.h, buf, len(POINTS), 1) == 0
-    ctx.reset_stats()
+    ctx.reset_stats(); ctx.set_timing(1)
     ctx.clear(); ctx.render(wl["view"], 1, spp); ctx.synchronize()
     assert lib.ptmi_lane_tally(ctx.h, buf, len(POINTS), 1) == 0
-    st = ctx.stats()
+    st = ctx.stats(); ctx.set_timing(0)
+    print("k_shade %.3f ms in this (measurement) build" % st["shade_ms"])
     TT = ["OTHER", "LOAD1_slot_state", "LOAD2_material_and_hit_data", "SHADE_compute", "STAGE", "FLUSH_PRIMS_quads_root_box", "FLUSH_STORE", "RING_READ"]
     tb = (ctypes.c_uint64 * len(TT))()
     times = None
