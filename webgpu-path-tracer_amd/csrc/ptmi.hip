@@ -132,7 +132,7 @@ struct Tuning {
   int bvh_carry_last = 0;      // PTMI_BVH_CARRY_LAST: the last this-many steps carry nothing over (measured: 0 is best — the drain launch costs 1.5-2.5 ms either way)
   int bvh_carry_min_paths = 4 << 20, bvh_carry_min_depth = 12;  // PTMI_BVH_CARRY_MIN_PATHS / _MIN_DEPTH: batches and trees below these are traced without carrying (tests: 0)
   int sort = -1;               // PTMI_SORT: k_shade sorts its chunks by material class (-1 = when the scene has more than one)
-  bool shade_bins = false;     // PTMI_SHADE_BINS: k_shade bins the new rays by the signs of their direction (k_shade6b; one material class, progressive mode without importance sampling)
+  bool shade_loop = false;     // PTMI_SHADE_LOOP: k_shade keeps a path in its lane while its new rays need no tree walk (k_shade6l; one material class, progressive mode without importance sampling)
   int shade_blocks_per_cu = 0; // PTMI_SHADE_BLOCKS_PER_CU (0 = from the variant's occupancy)
   int tail_limit = -1;         // PTMI_TAIL_LIMIT: k_tail takes queues of at most this many slots (-1 = kTailLimitFirst / kTailLimitLater, 0 = never)
   bool render_ahead = true;    // PTMI_RENDER_AHEAD=0
@@ -170,7 +170,6 @@ struct ptmi_ctx {
   bool has_unknown_material = false;
   int material_classes = 0;      // distinct shade bins among the materials: k_shade sorts only when > 1
   int shade_blocks_per_cu[16] = {0};  // per k_shade variant: resident 256-thread blocks per CU (0 = not asked yet)
-  int shade_bins_blocks_per_cu = 0;   // k_shade6b: resident 512-thread blocks per CU (0 = not asked yet)
 
   int W = 0, H = 0;
   DBuf d_fb_own;
@@ -182,7 +181,7 @@ struct ptmi_ctx {
   bool pixsum_alloc = false;
   size_t slot_cap = 0;  // slots per queue buffer (paths + room for the holes k_shade's regions leave)
   DBuf d_q0[2], d_q1[2], d_q2[2], d_tp[2], d_hm[2];  // slot-indexed live state and hit records, ping-pong
-  DBuf d_uv, d_acc, d_pixsum, d_touched, d_ctl, d_totals, d_scratch, d_spill, d_heads, d_shade_park;
+  DBuf d_uv, d_acc, d_pixsum, d_touched, d_ctl, d_totals, d_scratch, d_spill, d_heads;
   DBuf d_carry[2];  // Carry: the pools of saved traversal state, ping-pong like the queues
   int ctl_cap = 0;
 
@@ -703,7 +702,6 @@ Paths paths_of(ptmi_ctx* c, int step, bool with_pixsum) {
   P.hin = HitBuf{c->d_tp[a].as<float2>(), c->d_hm[a].as<uint32_t>()};
   P.hout = HitBuf{c->d_tp[b].as<float2>(), c->d_hm[b].as<uint32_t>()};
   P.uv = c->d_uv.as<float2>();
-  P.shade_park = c->d_shade_park.as<float4>();
   P.acc = c->d_acc.as<float4>();
   P.pixsum = with_pixsum ? c->d_pixsum.as<float4>() : nullptr;
   P.touched = with_pixsum ? nullptr : c->d_touched.as<uint8_t>();  // NUM_SAMPLES == 1: acc[pid] is written lazily
@@ -751,7 +749,7 @@ void load_tuning(ptmi_ctx* c) {
   t.bvh_carry_min_paths = std::max(0, env_int("PTMI_BVH_CARRY_MIN_PATHS", t.bvh_carry_min_paths));
   t.bvh_carry_min_depth = std::max(0, env_int("PTMI_BVH_CARRY_MIN_DEPTH", t.bvh_carry_min_depth));
   t.sort = env_int("PTMI_SORT", -1);
-  t.shade_bins = env_int("PTMI_SHADE_BINS", t.shade_bins ? 1 : 0) != 0;
+  t.shade_loop = env_int("PTMI_SHADE_LOOP", t.shade_loop ? 1 : 0) != 0;
   t.shade_blocks_per_cu = env_int("PTMI_SHADE_BLOCKS_PER_CU", 0);
   t.tail_limit = env_int("PTMI_TAIL_LIMIT", -1);
   t.render_ahead = env_int("PTMI_RENDER_AHEAD", 1) != 0;
@@ -963,17 +961,8 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
     shade_bpc = cached;
   }
   const uint32_t sgrid = std::max<uint32_t>(1, std::min<uint32_t>((bound + kSChunk - 1) / kSChunk, (uint32_t)c->num_cus * (uint32_t)std::min(8, std::max(1, shade_bpc))));  // <= 8: the queue buffers' slack is sized for that (ensure_paths)
-  // the binned variant (k_shade6b): one material class, progressive mode without importance sampling; 512-thread blocks, three per CU
-  const bool shade_bins = c->tun.shade_bins && !sort && !p.importance_sampling && !shade_multi;
-  if (shade_bins && c->shade_bins_blocks_per_cu == 0) {
-    int nb = 0;
-    const void* k = c->counters ? reinterpret_cast<const void*>(&k_shade6b<true>) : reinterpret_cast<const void*>(&k_shade6b<false>);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, kBinBlock, 0) != hipSuccess || nb < 1) nb = 2;
-    c->shade_bins_blocks_per_cu = std::min(nb, 3);
-    if (c->tun.debug_placement) fprintf(stderr, "ptmi: k_shade6b: %d blocks of %d threads per CU\n", nb, kBinBlock);
-  }
-  const uint32_t bgrid = std::max<uint32_t>(1, std::min<uint32_t>((bound + kBinBlock - 1) / kBinBlock, (uint32_t)c->num_cus * (uint32_t)std::max(1, c->shade_bins_blocks_per_cu)));
-  if (shade_bins) HIP_TRY(c, c->d_shade_park.ensure((size_t)c->num_cus * 3u * kBinBlock * 3u * sizeof(float4)));  // three entries per thread of the largest grid: where a survivor waits for a full bin
+  // the loop form (k_shade6l): progressive mode without importance sampling, one material class
+  const bool shade_loop = c->tun.shade_loop && !sort && !p.importance_sampling && !shade_multi;
   unsigned long long* tot = c->d_totals.as<unsigned long long>();
   // queues of at most this many slots are traced to the end by one k_tail launch instead of a k_bvh + k_shade pair per bounce
   // (a whole small batch — a lone 1080p frame — at step 0; later steps hand over only their thin ends: on deep trees a lane-per-path
@@ -1046,9 +1035,9 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
       else PTMI_LAUNCH_SHADE(IS, SO, false, false);         \
     }                                                       \
   } while (0)
-      if (shade_bins) {
-        if (c->counters) hipLaunchKernelGGL((k_shade6b<true>), dim3(bgrid), dim3(kBinBlock), 0, c->stream, c->S, rc, P, ctl + s, c->d_heads.as<uint32_t>(), tot, s == 0 ? 1 : 0, s == 0 ? 0u : resv);
-        else hipLaunchKernelGGL((k_shade6b<false>), dim3(bgrid), dim3(kBinBlock), 0, c->stream, c->S, rc, P, ctl + s, c->d_heads.as<uint32_t>(), tot, s == 0 ? 1 : 0, s == 0 ? 0u : resv);
+      if (shade_loop) {
+        if (c->counters) hipLaunchKernelGGL((k_shade6l<true>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, c->d_heads.as<uint32_t>(), tot, s == 0 ? 1 : 0, s == 0 ? 0u : resv);
+        else hipLaunchKernelGGL((k_shade6l<false>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, c->d_heads.as<uint32_t>(), tot, s == 0 ? 1 : 0, s == 0 ? 0u : resv);
       } else if (p.importance_sampling) {
         if (sort) PTMI_LAUNCH_SHADE2(true, true);
         else PTMI_LAUNCH_SHADE2(true, false);
@@ -1542,7 +1531,7 @@ void ptmi_destroy(ptmi_ctx* c) {
   for (DBuf* b : {&c->d_quad_unit_n, &c->d_spheres, &c->d_sphere_info, &c->d_quads, &c->d_quad_mat, &c->d_tris, &c->d_pretri, &c->d_trinorm, &c->d_meshes, &c->d_xforms,
                   &c->d_mats, &c->d_pairs, &c->d_leaf_table, &c->d_fb_own, &c->d_q0[0], &c->d_q0[1], &c->d_q1[0], &c->d_q1[1], &c->d_q2[0],
                   &c->d_q2[1], &c->d_tp[0], &c->d_tp[1], &c->d_hm[0], &c->d_hm[1], &c->d_uv, &c->d_acc, &c->d_pixsum, &c->d_touched, &c->d_ctl, &c->d_totals,
-                  &c->d_scratch, &c->d_spill, &c->d_heads, &c->d_shade_park, &c->d_fb_gather, &c->d_fb_stage, &c->d_bvh_rows, &c->d_carry[0], &c->d_carry[1]})
+                  &c->d_scratch, &c->d_spill, &c->d_heads, &c->d_fb_gather, &c->d_fb_stage, &c->d_bvh_rows, &c->d_carry[0], &c->d_carry[1]})
     b->release();
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c->worker;

@@ -38,8 +38,8 @@ DEV void lane_tally() {
 // ... and a stopwatch per wave: TT(k, dep) closes the interval that began at the previous mark and charges it to region k; `dep` is a value the mark must wait
 // for (the asm takes it as an operand, so the compiler puts the s_waitcnt for its load in front of the clock read).  Where do a wave's cycles go?
 constexpr int kTimeTallies = 12;
-__shared__ unsigned long long s_time_tally[8 * kTimeTallies];  // per wave of the block (up to 8: k_shade6b): cycles per region
-__shared__ unsigned long long s_time_last[8];
+__shared__ unsigned long long s_time_tally[4 * kTimeTallies];  // per wave of the block: cycles per region
+__shared__ unsigned long long s_time_last[4];
 __device__ unsigned long long g_time_tally[2 * kTimeTallies];  // {cycles, marks} per region
 template <int K>
 DEV void time_tally(float dep) {
@@ -305,7 +305,6 @@ struct Paths {
   uint8_t* touched;  // by path id, NUM_SAMPLES == 1 only (else null): 0 = acc[pid] has never been written and stands for (0,0,0) — the
                      // batch starts with one small memset of these flags instead of k_generate streaming 16 bytes of zeros per path
   uint32_t cap;      // slots per queue buffer
-  float4* shade_park;  // k_shade6b only: three entries per thread of its grid (a new ray's state while its bin is full)
 };
 
 // One 128-byte line per step: k_shade's blocks and waves claim their output regions of the NEXT step's queue with atomics on n_rays, and

@@ -1041,41 +1041,24 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
   if (COUNT) reduce_counters(cn, totals, false);
 }
 
-// ray_color's loop body for scenes with one material class, with the new rays BINNED BY THE SIGNS OF THEIR DIRECTION before hitScene part 1 (round 5).
-// hit_quad's first test — `dot(dir, normal) > 0`: the quad faces away — halves the lanes of every quad's pass, but a wave skips the rest of a quad only when ALL
-// of its lanes agree; after a diffuse bounce the 64 rays of a flush pass point everywhere, so each of configs[1]'s six walls costs its 74 instructions at 32, then
-// 25 lanes (NOTES_r04 §1: 37 % of the kernel's cycles).  Rays whose directions share their three signs agree on every axis-aligned quad: three of the six
-// walls of a Cornell box are skipped by the whole wave after 7 instructions, the other three run with every lane in use.  A wave's ring of 128 entries cannot
-// feed eight bins, so the EIGHT waves of a 512-thread block share eight rings of 128 (the same 6 KB of LDS per wave), barrier-free:
-//   * a survivor takes the next position p of its bin (one LDS atomic per lane), waits until cell p & 127 is free, writes its state and publishes it
-//     (per-cell sequence numbers, the bounded multi-producer queue of D. Vyukov: a cell holds p when position p may be written, p + 1 when it was,
-//     p + 128 once it was consumed);
-//   * the wave whose lane took the LAST position of a 64-entry chunk (p & 63 == 63) owes that chunk its flush pass: it waits until the 64 cells are
-//     published, runs hitScene part 1 on them — always 64 lanes, one direction octant — and frees the cells;
-//   * both waits are polls in one loop that also serves the wave's other duties, and the lowest unconsumed complete chunk of a bin can always be completed
-//     (the cells its positions wait for belong to a chunk below it: consumed), so some wave always makes progress;
-//   * what is left in the bins at the end (fewer than 64 each) goes out in partial passes after the block's only barrier, bin b by wave b.
-// Which slot of the next queue a path lands in changes — nothing else: paths are independent and find their pixel by path id.
-constexpr int kBinBlock = 512;
+// ray_color's loop AS A LOOP (round 5): a lane keeps its path from bounce to bounce for as long as the new ray needs no tree walk, and only rays that entered
+// the BVH's root box travel through the next step's queue (to k_bvh and back).  k_shade is bound by the memory system, not by instruction issue — 16 more
+// bytes per ray cost it 6-8 %, half of the flush pass's instructions taken away cost nothing (profiles/r05_shade_bins_ab.txt) — and the per-bounce form moves
+// 120 bytes of path state per ray and bounce through HBM whether the ray meets a triangle or not; on configs[1] one new ray in twelve does.  Per iteration:
+//   A  the lanes whose ray has its final hit record run ray_color's body (shade_one);
+//   B  idle lanes take new slots from the wave's input groups once kLoopRefill of them wait (their loads travel during C);
+//   C  hitScene part 1 for the survivors' new rays; definite misses end here (traceRay.wgsl:12-16), the others become the lane's state;
+//   D  lanes whose new ray entered the root box write their state to the wave's output region of the next queue and fall idle.
+// Same device functions, same arithmetic per ray, same tallies; a path simply is where it is — queues hold rays of any bounce (as they do since Carry).
+constexpr int kLoopRefill = 16;
 template <bool IS, bool COUNT, bool MULTI>
-DEV void shade_body_bins(const DevScene& S, const RenderConst& rc, const Paths& P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads,
+DEV void shade_body_loop(const DevScene& S, const RenderConst& rc, const Paths& P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads,
                          unsigned long long* __restrict__ totals, int first, uint32_t resv) {
   reset_heads(heads);
-  constexpr uint32_t kBins = 8, kCap = 128, kWaves = kBinBlock / 64;
-  static_assert(kWaves == kBins, "bin b's leftovers are flushed by wave b");
-  __shared__ float4 s_q0[kBins * kCap], s_q1[kBins * kCap], s_q2[kBins * kCap];
-  __shared__ uint32_t s_seq[kBins * kCap];
-  __shared__ uint32_t s_tail[kBins];
+  constexpr uint32_t kWaves = kBlock / 64;
   constexpr uint32_t kR0Empty = 0xffffffffu, kR0Busy = 0xfffffffeu, kR0Full = 0xfffffffdu;
   __shared__ uint32_t s_region0;  // the waves' first regions: one claim per block (see shade_body)
   if (threadIdx.x == 0) s_region0 = kR0Empty;
-  if (threadIdx.x < kBins) s_tail[threadIdx.x] = 0u;
-  for (uint32_t i = threadIdx.x; i < kBins * kCap; i += kBinBlock) s_seq[i] = i & (kCap - 1u);
-#ifdef PTMI_LANE_TALLY
-  if (threadIdx.x < kLaneTallies * 2) s_lane_tally[threadIdx.x] = 0u;
-  if (threadIdx.x < 8 * kTimeTallies) s_time_tally[threadIdx.x] = 0ull;
-  if (threadIdx.x < 8) s_time_last[threadIdx.x] = 0ull;
-#endif
   __syncthreads();
   const QuadL L = load_light(S);
   const int lane = lane_id();
@@ -1083,44 +1066,85 @@ DEV void shade_body_bins(const DevScene& S, const RenderConst& rc, const Paths& 
   const uint32_t n_carried = resv ? min(ctl->n_carried, resv) : 0u;  // (Carry: slots [n_carried, resv) of this queue hold nothing)
   uint32_t n = ctl->n_rays;
   if (n <= resv && n_carried == 0u) n = 0u;
-  constexpr uint32_t kChunk = 64u * kWaves;  // slots the block's waves take per round, a 64-slot group each
-  const uint32_t region = max(128u * kWaves, ((n / gridDim.x / kRegionDiv) + (128u * kWaves - 1u)) / (128u * kWaves) * (128u * kWaves));
+  const uint32_t region = max((uint32_t)kSChunk, ((n / gridDim.x / kRegionDiv) + 511u) & ~511u);
   const uint32_t wregion = region / kWaves;
   uint32_t w_cur = 0, w_rend = 0;  // this wave's current output region of the next queue (wave-uniform)
-  uint32_t my_valid = 0, my_missed = 0;
+  uint32_t tally = 0;              // hitScene invocations
   Counters cn = {0, 0, 0, 0, 0};
-  auto seq_load = [&](uint32_t i) { return __hip_atomic_load(&s_seq[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); };
-  auto seq_store = [&](uint32_t i, uint32_t v) { __hip_atomic_store(&s_seq[i], v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); };
-  // hitScene part 1 for the entries in cells `q` (one per lane, the first `take` lanes); settles definite misses, places the others in the next queue.
-  // The entries are taken into registers and the cells handed back at once (`free_as` = their next sequence number): a bin is two chunks long, and a cell
-  // held for the length of this pass would stall the lanes that take the positions 128 further on.
-  auto flush_pass = [&](uint32_t q, uint32_t take, uint32_t free_as) {
-    bool keep = false;
-    float2 tp = make_float2(0.0f, 0.0f);
-    uint32_t hm = 0u;
-    float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0;
-    if ((uint32_t)lane < take) {
-      a0 = s_q0[q], a1 = s_q1[q], a2 = s_q2[q];
-      seq_store(q, free_as);
+  SlotState st;
+  st.q0 = st.q1 = st.q2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  st.tp = make_float2(0.0f, 0.0f);
+  st.hitmat = HITMAT_HOLE, st.slot = 0;
+  bool busy = false;   // the lane holds a path
+  bool fresh = false;  // ... whose state was asked for in B of the last iteration and has not been looked at yet
+  // input: 64-slot groups dealt round-robin to the grid's waves; `pos` slots of the open group are taken
+  const uint32_t gstride = gridDim.x * kWaves;
+  uint32_t gnext = blockIdx.x * kWaves + wv, gbase = 0, pos = 64;
+#pragma unroll 1
+  for (;;) {
+    // ---- A: ray_color's loop body ----
+    if (fresh) {  // a slot of the queue: its hit record is final (k_bvh leaves HITMAT_BVH standing where no triangle won)
+      if (__float_as_uint(st.q1.w) == PID_HOLE) busy = false;
+      st.hitmat &= ~HITMAT_BVH;
+      fresh = false;
     }
-    TT(TT_RING_READ, a0.x + a1.x + a2.x);
-    if ((uint32_t)lane < take) {
-      LT(LT_FLUSH);
-      uint32_t rng = __float_as_uint(a0.w);
-      prims_for_ray<COUNT>(S, mk3(a0), mk3(a1), rng, tp, hm, cn);
-      a0.w = __uint_as_float(rng);
-      TT(TT_FLUSH_PRIMS, tp.x + __uint_as_float(hm));
-      if (kMissShortcut && !MULTI && hm == HITMAT_MISS) {  // traceRay.wgsl:12-16 (see shade_body)
-        LT(LT_MISS_SHORTCUT);
-        end_sample_progressive(P, __float_as_uint(a1.w), mk3(rc.bg[0], rc.bg[1], rc.bg[2]) * mk3(a2), (__float_as_int(a2.w) & kAccWritten) != 0);
-      } else {
-        keep = true;
+    const bool go = busy && (st.hitmat & HITMAT_BVH) == 0u;
+    NewState ns;
+    ns.o = ns.d = ns.T = mk3(0, 0, 0);
+    ns.bounce = 0, ns.rng = 0, ns.pid = 0;
+    bool survive = false;
+    if (go) {
+      tally++;
+      const TriFetch tf = tri_fetch(S, P.uv, st.slot, __float_as_uint(st.tp.y));  // (a triangle hit can only be a ray that came through the queue: its slot's barycentrics)
+      survive = shade_one<IS, MULTI>(S, rc, P, st, tf, L, ns);
+      busy = survive;
+    }
+    // ---- B: idle lanes take new slots ----
+    {
+      const uint64_t bm = __ballot(busy);
+      const uint32_t nidle = 64u - (uint32_t)__popcll(bm);
+      if (nidle >= (uint32_t)kLoopRefill || bm == 0ull) {
+        if (pos == 64u && gnext * 64u < n) {
+          gbase = gnext * 64u;
+          gnext += gstride;
+          pos = 0;
+        }
+        if (pos < 64u) {
+          const uint32_t take = min(nidle, 64u - pos), rank = lanes_below(~bm);
+          if (!busy && rank < take) {
+            const uint32_t slot = gbase + pos + rank;
+            if (slot < n && !dead_slot(slot, n_carried, resv)) {
+              st = load_slot(P, slot, first != 0, rc);
+              busy = true;
+              fresh = true;
+            }
+          }
+          pos += take;
+        }
       }
     }
-    const uint64_t km = __ballot(keep);
-    const uint32_t kept = (uint32_t)__popcll(km);
-    my_missed += take - kept;
-    if (kept) {
+    // ---- C: hitScene part 1 for the survivors' new rays ----
+    if (survive) {
+      uint32_t rng = ns.rng, hm;
+      float2 tp;
+      prims_for_ray<COUNT>(S, ns.o, ns.d, rng, tp, hm, cn);
+      if (kMissShortcut && !MULTI && hm == HITMAT_MISS) {  // traceRay.wgsl:12-16 (see shade_body)
+        end_sample_progressive(P, ns.pid, mk3(rc.bg[0], rc.bg[1], rc.bg[2]) * ns.T, (ns.bounce & kAccWritten) != 0);
+        tally++;
+        busy = false;
+      } else {
+        st.q0 = make_float4(ns.o.x, ns.o.y, ns.o.z, __uint_as_float(rng));
+        st.q1 = make_float4(ns.d.x, ns.d.y, ns.d.z, __uint_as_float(ns.pid));
+        st.q2 = make_float4(ns.T.x, ns.T.y, ns.T.z, __int_as_float(ns.bounce));
+        st.tp = tp;
+        st.hitmat = hm;
+      }
+    }
+    // ---- D: rays that entered the root box go to the next queue ----
+    const bool ex = busy && !fresh && (st.hitmat & HITMAT_BVH) != 0u;
+    const uint64_t km = __ballot(ex);
+    if (km) {
+      const uint32_t kept = (uint32_t)__popcll(km);
       const uint32_t rank = lanes_below(km);
       const uint32_t b0 = w_cur, n0 = min(kept, w_rend - w_cur);
       uint32_t b1 = 0xffffffffu;
@@ -1128,7 +1152,7 @@ DEV void shade_body_bins(const DevScene& S, const RenderConst& rc, const Paths& 
       if (kept > n0) {  // claim the wave's next region for the rest
         uint32_t nb = 0;
         bool full;
-        if (w_rend == 0u) {  // the wave's first region: its share of the block's claim
+        if (w_rend == 0u) {  // the wave's first region: its quarter of the block's claim
           if (lane == 0) nb = atomicCAS(&s_region0, kR0Empty, kR0Busy);
           nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
           if (nb == kR0Empty) {
@@ -1166,132 +1190,24 @@ DEV void shade_body_bins(const DevScene& S, const RenderConst& rc, const Paths& 
           w_rend = nb + wregion;
         }
       }
-      if (keep && (rank < n0 || b1 != 0xffffffffu)) {
-        LT(LT_KEEP);
-        const uint32_t dst = (rank < n0) ? (b0 + rank) : (b1 + (rank - n0));
-        P.out.q0[dst] = a0;
-        P.out.q1[dst] = a1;
-        P.out.q2[dst] = a2;
-        P.hout.tp[dst] = tp;
-        P.hout.mat[dst] = hm;
+      if (ex) {
+        if (rank < n0 || b1 != 0xffffffffu) {
+          const uint32_t dst = (rank < n0) ? (b0 + rank) : (b1 + (rank - n0));
+          P.out.q0[dst] = st.q0;
+          P.out.q1[dst] = st.q1;
+          P.out.q2[dst] = st.q2;
+          P.hout.tp[dst] = st.tp;
+          P.hout.mat[dst] = st.hitmat;
+        }
+        busy = false;
       }
     }
-    TT(TT_FLUSH_STORE, 0.0f);
-  };
-  {
-    uint32_t base = blockIdx.x * kChunk;
-    auto fetch = [&](SlotState& st) {  // -> this lane's slot of the wave's group of chunk `base` holds something; its state is on its way then
-      const uint32_t j = wv * 64u + (uint32_t)lane;
-      const bool act = base < n && j < min(kChunk, n - base) && !dead_slot(base + j, n_carried, resv);
-      if (act) st = load_slot(P, base + j, first != 0, rc);
-      return act;
-    };
-    auto park_of = [&]() { return P.shade_park + ((size_t)blockIdx.x * kBinBlock + threadIdx.x) * 3u; };  // this lane's three entries of the overflow area (below; made where it is needed: two registers less across the loop)
-    SlotState cur;
-    bool cur_act = false;
-    bool have = base < n;
-    if (have) cur_act = fetch(cur);
-#pragma unroll 1
-    while (have) {
-      // ---- ray_color's loop body for the group ----
-      bool survive = false, valid = false;
-      NewState ns;
-      ns.o = ns.d = ns.T = mk3(0, 0, 0);
-      ns.bounce = 0, ns.rng = 0, ns.pid = 0;
-      TT(TT_OTHER, 0.0f);  // (polls, sleeps, loop bookkeeping since the last mark)
-      if (cur_act) {
-        LT(LT_GROUP);
-        TT(TT_LOAD1, cur.q0.x + cur.q1.x + cur.q2.x + cur.tp.x + __uint_as_float(cur.hitmat));
-        valid = __float_as_uint(cur.q1.w) != PID_HOLE;
-        if (valid) {
-          LT(LT_VALID);
-          const TriFetch tf = tri_fetch(S, P.uv, cur.slot, __float_as_uint(cur.tp.y));
-          survive = shade_one<IS, MULTI>(S, rc, P, cur, tf, L, ns);
-        }
-      }
-      TT(TT_SHADE, ns.o.x + ns.T.x);
-      my_valid += (uint32_t)__popcll(__ballot(valid));
-      // ---- survivors into their bins ----
-      const uint32_t bin = (ns.d.x < 0.0f ? 1u : 0u) | (ns.d.y < 0.0f ? 2u : 0u) | (ns.d.z < 0.0f ? 4u : 0u);
-      uint32_t p = 0u;
-      if (survive) {
-        LT(LT_STAGE);
-        p = atomicAdd(&s_tail[bin], 1u);
-      }
-      const uint32_t cell = bin * kCap + (p & (kCap - 1u));
-      bool pend = survive;
-      if (pend && seq_load(cell) == p) {  // the cell's previous tenant (position p - 128) was consumed: nearly always
-        s_q0[cell] = make_float4(ns.o.x, ns.o.y, ns.o.z, __uint_as_float(ns.rng));
-        s_q1[cell] = make_float4(ns.d.x, ns.d.y, ns.d.z, __uint_as_float(ns.pid));
-        s_q2[cell] = make_float4(ns.T.x, ns.T.y, ns.T.z, __int_as_float(ns.bounce));
-        seq_store(cell, p + 1u);
-        pend = false;
-      }
-      if (pend) {  // a full bin (128 entries ahead of its consumers): the state waits in the lane's overflow entries, not in registers across the flush passes below
-        float4* const park = park_of();
-        park[0] = make_float4(ns.o.x, ns.o.y, ns.o.z, __uint_as_float(ns.rng));
-        park[1] = make_float4(ns.d.x, ns.d.y, ns.d.z, __uint_as_float(ns.pid));
-        park[2] = make_float4(ns.T.x, ns.T.y, ns.T.z, __int_as_float(ns.bounce));
-      }
-      uint64_t own = __ballot(survive && (p & 63u) == 63u);  // chunks whose last position one of this wave's lanes took: theirs to flush
-      TT(TT_STAGE, __uint_as_float(p));
-      // ---- the next group's state is requested now: the loads travel during the flush passes (see shade_body_wave) ----
-      base += gridDim.x * kChunk;
-      have = base < n;
-      SlotState nxt;
-      bool nxt_act = false;
-      if (have) nxt_act = fetch(nxt);
-      // ---- duties: waiting lanes into their cells as these come free, owned chunks flushed as they become complete — polls, all of them in turn ----
-      uint32_t rot = 0;
-#pragma unroll 1
-      for (;;) {
-        if (pend && seq_load(cell) == p) {
-          const float4* const park = park_of();
-          s_q0[cell] = park[0];
-          s_q1[cell] = park[1];
-          s_q2[cell] = park[2];
-          seq_store(cell, p + 1u);
-          pend = false;
-        }
-        const uint64_t pm = __ballot(pend);
-        if (!pm && !own) break;
-        if (own) {
-          uint64_t at = own & ~((1ull << (rot & 63u)) - 1ull);
-          if (!at) at = own;
-          const int l = __ffsll((unsigned long long)at) - 1;
-          rot = (uint32_t)l + 1u;
-          const uint32_t pb = (uint32_t)__shfl((int)p, l, 64) - 63u, ob = (uint32_t)__shfl((int)bin, l, 64);
-          const uint32_t i = ob * kCap + ((pb + (uint32_t)lane) & (kCap - 1u));
-          const bool ready = seq_load(i) == pb + (uint32_t)lane + 1u;
-          if (__ballot(ready) == ~0ull) {
-            flush_pass(i, 64u, pb + (uint32_t)lane + kCap);
-            own &= ~(1ull << l);
-            continue;
-          }
-        }
-        __builtin_amdgcn_s_sleep(2);
-      }
-      cur = nxt;
-      cur_act = nxt_act;
-    }
+    if (__ballot(busy) == 0ull && pos == 64u && gnext * 64u >= n) break;  // nothing in flight, nothing left to take
   }
-  __syncthreads();  // every survivor is in its bin, every complete chunk was flushed; the block's claim, if any wave made one, is in s_region0
-  {
-    const uint32_t t = s_tail[wv], take = t & 63u;
-    if (take) flush_pass(wv * kCap + ((t - take + (uint32_t)lane) & (kCap - 1u)), take, t - take + (uint32_t)lane + kCap);
-  }
-  if (MULTI) my_missed = 0;  // (no path ends in the flush phase then)
-  if (lane == 0 && my_missed + my_valid) atomicAdd(tally_line(totals, blockIdx.x), my_missed + my_valid);
-  __syncthreads();  // (a leftover pass may have made the block's claim)
-#ifdef PTMI_LANE_TALLY
-  if (threadIdx.x < kLaneTallies * 2 && s_lane_tally[threadIdx.x]) atomicAdd(&g_lane_tally[threadIdx.x], (unsigned long long)s_lane_tally[threadIdx.x]);
-  if (threadIdx.x < kTimeTallies) {
-    unsigned long long t = 0;
-    for (int w = 0; w < 8; w++) t += s_time_tally[w * kTimeTallies + threadIdx.x];
-    if (t) atomicAdd(&g_time_tally[threadIdx.x], t);
-  }
-#endif
-  if (w_rend == 0u && s_region0 < kR0Full) {  // never needed a region: all of this wave's share of the block's claim becomes holes
+  for (int off2 = 32; off2 > 0; off2 >>= 1) tally += __shfl_down(tally, off2, 64);
+  if (lane == 0 && tally) atomicAdd(tally_line(totals, blockIdx.x), tally);
+  __syncthreads();  // the block's claim, if any wave made one, is in s_region0 now
+  if (w_rend == 0u && s_region0 < kR0Full) {  // never needed a region: all of this wave's quarter of the block's claim becomes holes
     w_cur = s_region0 + wv * wregion;
     w_rend = w_cur + wregion;
   }
@@ -1317,11 +1233,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) 
   else shade_body_wave<false, COUNT, false>(S, rc, P, ctl, heads, totals, first, resv);
 }
 
-// ... and the binned variant for the 80-VGPR case (512-thread blocks, three per CU)
+// ... and the loop form of the 80-VGPR case
 template <bool COUNT>
-__global__ __launch_bounds__(kBinBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_shade6b(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl,
-                                                                                                    uint32_t* __restrict__ heads, unsigned long long* __restrict__ totals, int first, uint32_t resv) {
-  shade_body_bins<false, COUNT, false>(S, rc, P, ctl, heads, totals, first, resv);
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_shade6l(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl,
+                                                                                                 uint32_t* __restrict__ heads, unsigned long long* __restrict__ totals, int first, uint32_t resv) {
+  shade_body_loop<false, COUNT, false>(S, rc, P, ctl, heads, totals, first, resv);
 }
 
 // k_tail — a SHORT queue traced to the end in one launch: every lane takes a path and runs ray_color's loop for it (hitScene part 2 on
