@@ -132,7 +132,6 @@ struct Tuning {
   int bvh_carry_last = 0;      // PTMI_BVH_CARRY_LAST: the last this-many steps carry nothing over (measured: 0 is best — the drain launch costs 1.5-2.5 ms either way)
   int bvh_carry_min_paths = 4 << 20, bvh_carry_min_depth = 12;  // PTMI_BVH_CARRY_MIN_PATHS / _MIN_DEPTH: batches and trees below these are traced without carrying (tests: 0)
   int sort = -1;               // PTMI_SORT: k_shade sorts its chunks by material class (-1 = when the scene has more than one)
-  bool shade_loop = false;     // PTMI_SHADE_LOOP: k_shade keeps a path in its lane while its new rays need no tree walk (k_shade6l; one material class, progressive mode without importance sampling)
   int shade_blocks_per_cu = 0; // PTMI_SHADE_BLOCKS_PER_CU (0 = from the variant's occupancy)
   int tail_limit = -1;         // PTMI_TAIL_LIMIT: k_tail takes queues of at most this many slots (-1 = kTailLimitFirst / kTailLimitLater, 0 = never)
   bool render_ahead = true;    // PTMI_RENDER_AHEAD=0
@@ -749,7 +748,6 @@ void load_tuning(ptmi_ctx* c) {
   t.bvh_carry_min_paths = std::max(0, env_int("PTMI_BVH_CARRY_MIN_PATHS", t.bvh_carry_min_paths));
   t.bvh_carry_min_depth = std::max(0, env_int("PTMI_BVH_CARRY_MIN_DEPTH", t.bvh_carry_min_depth));
   t.sort = env_int("PTMI_SORT", -1);
-  t.shade_loop = env_int("PTMI_SHADE_LOOP", t.shade_loop ? 1 : 0) != 0;
   t.shade_blocks_per_cu = env_int("PTMI_SHADE_BLOCKS_PER_CU", 0);
   t.tail_limit = env_int("PTMI_TAIL_LIMIT", -1);
   t.render_ahead = env_int("PTMI_RENDER_AHEAD", 1) != 0;
@@ -961,8 +959,6 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
     shade_bpc = cached;
   }
   const uint32_t sgrid = std::max<uint32_t>(1, std::min<uint32_t>((bound + kSChunk - 1) / kSChunk, (uint32_t)c->num_cus * (uint32_t)std::min(8, std::max(1, shade_bpc))));  // <= 8: the queue buffers' slack is sized for that (ensure_paths)
-  // the loop form (k_shade6l): progressive mode without importance sampling, one material class
-  const bool shade_loop = c->tun.shade_loop && !sort && !p.importance_sampling && !shade_multi;
   unsigned long long* tot = c->d_totals.as<unsigned long long>();
   // queues of at most this many slots are traced to the end by one k_tail launch instead of a k_bvh + k_shade pair per bounce
   // (a whole small batch — a lone 1080p frame — at step 0; later steps hand over only their thin ends: on deep trees a lane-per-path
@@ -1035,10 +1031,7 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
       else PTMI_LAUNCH_SHADE(IS, SO, false, false);         \
     }                                                       \
   } while (0)
-      if (shade_loop) {
-        if (c->counters) hipLaunchKernelGGL((k_shade6l<true>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, c->d_heads.as<uint32_t>(), tot, s == 0 ? 1 : 0, s == 0 ? 0u : resv);
-        else hipLaunchKernelGGL((k_shade6l<false>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl + s, c->d_heads.as<uint32_t>(), tot, s == 0 ? 1 : 0, s == 0 ? 0u : resv);
-      } else if (p.importance_sampling) {
+      if (p.importance_sampling) {
         if (sort) PTMI_LAUNCH_SHADE2(true, true);
         else PTMI_LAUNCH_SHADE2(true, false);
       } else {

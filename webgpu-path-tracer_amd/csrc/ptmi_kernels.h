@@ -1041,183 +1041,14 @@ DEV void shade_body_wave(const DevScene& S, const RenderConst& rc, const Paths& 
   if (COUNT) reduce_counters(cn, totals, false);
 }
 
-// ray_color's loop AS A LOOP (round 5): a lane keeps its path from bounce to bounce for as long as the new ray needs no tree walk, and only rays that entered
-// the BVH's root box travel through the next step's queue (to k_bvh and back).  k_shade is bound by the memory system, not by instruction issue — 16 more
-// bytes per ray cost it 6-8 %, half of the flush pass's instructions taken away cost nothing (profiles/r05_shade_bins_ab.txt) — and the per-bounce form moves
-// 120 bytes of path state per ray and bounce through HBM whether the ray meets a triangle or not; on configs[1] one new ray in twelve does.  Per iteration:
-//   A  the lanes whose ray has its final hit record run ray_color's body (shade_one);
-//   B  idle lanes take new slots from the wave's input groups once kLoopRefill of them wait (their loads travel during C);
-//   C  hitScene part 1 for the survivors' new rays; definite misses end here (traceRay.wgsl:12-16), the others become the lane's state;
-//   D  lanes whose new ray entered the root box write their state to the wave's output region of the next queue and fall idle.
-// Same device functions, same arithmetic per ray, same tallies; a path simply is where it is — queues hold rays of any bounce (as they do since Carry).
-constexpr int kLoopRefill = 16;
-template <bool IS, bool COUNT, bool MULTI>
-DEV void shade_body_loop(const DevScene& S, const RenderConst& rc, const Paths& P, StepCtl* __restrict__ ctl, uint32_t* __restrict__ heads,
-                         unsigned long long* __restrict__ totals, int first, uint32_t resv) {
-  reset_heads(heads);
-  constexpr uint32_t kWaves = kBlock / 64;
-  constexpr uint32_t kR0Empty = 0xffffffffu, kR0Busy = 0xfffffffeu, kR0Full = 0xfffffffdu;
-  __shared__ uint32_t s_region0;  // the waves' first regions: one claim per block (see shade_body)
-  if (threadIdx.x == 0) s_region0 = kR0Empty;
-  __syncthreads();
-  const QuadL L = load_light(S);
-  const int lane = lane_id();
-  const uint32_t wv = threadIdx.x >> 6;
-  const uint32_t n_carried = resv ? min(ctl->n_carried, resv) : 0u;  // (Carry: slots [n_carried, resv) of this queue hold nothing)
-  uint32_t n = ctl->n_rays;
-  if (n <= resv && n_carried == 0u) n = 0u;
-  const uint32_t region = max((uint32_t)kSChunk, ((n / gridDim.x / kRegionDiv) + 511u) & ~511u);
-  const uint32_t wregion = region / kWaves;
-  uint32_t w_cur = 0, w_rend = 0;  // this wave's current output region of the next queue (wave-uniform)
-  uint32_t tally = 0;              // hitScene invocations
-  Counters cn = {0, 0, 0, 0, 0};
-  SlotState st;
-  st.q0 = st.q1 = st.q2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  st.tp = make_float2(0.0f, 0.0f);
-  st.hitmat = HITMAT_HOLE, st.slot = 0;
-  bool busy = false;   // the lane holds a path
-  bool fresh = false;  // ... whose state was asked for in B of the last iteration and has not been looked at yet
-  // input: 64-slot groups dealt round-robin to the grid's waves; `pos` slots of the open group are taken
-  const uint32_t gstride = gridDim.x * kWaves;
-  uint32_t gnext = blockIdx.x * kWaves + wv, gbase = 0, pos = 64;
-#pragma unroll 1
-  for (;;) {
-    // ---- A: ray_color's loop body ----
-    if (fresh) {  // a slot of the queue: its hit record is final (k_bvh leaves HITMAT_BVH standing where no triangle won)
-      if (__float_as_uint(st.q1.w) == PID_HOLE) busy = false;
-      st.hitmat &= ~HITMAT_BVH;
-      fresh = false;
-    }
-    const bool go = busy && (st.hitmat & HITMAT_BVH) == 0u;
-    NewState ns;
-    ns.o = ns.d = ns.T = mk3(0, 0, 0);
-    ns.bounce = 0, ns.rng = 0, ns.pid = 0;
-    bool survive = false;
-    if (go) {
-      tally++;
-      const TriFetch tf = tri_fetch(S, P.uv, st.slot, __float_as_uint(st.tp.y));  // (a triangle hit can only be a ray that came through the queue: its slot's barycentrics)
-      survive = shade_one<IS, MULTI>(S, rc, P, st, tf, L, ns);
-      busy = survive;
-    }
-    // ---- B: idle lanes take new slots ----
-    {
-      const uint64_t bm = __ballot(busy);
-      const uint32_t nidle = 64u - (uint32_t)__popcll(bm);
-      if (nidle >= (uint32_t)kLoopRefill || bm == 0ull) {
-        if (pos == 64u && gnext * 64u < n) {
-          gbase = gnext * 64u;
-          gnext += gstride;
-          pos = 0;
-        }
-        if (pos < 64u) {
-          const uint32_t take = min(nidle, 64u - pos), rank = lanes_below(~bm);
-          if (!busy && rank < take) {
-            const uint32_t slot = gbase + pos + rank;
-            if (slot < n && !dead_slot(slot, n_carried, resv)) {
-              st = load_slot(P, slot, first != 0, rc);
-              busy = true;
-              fresh = true;
-            }
-          }
-          pos += take;
-        }
-      }
-    }
-    // ---- C: hitScene part 1 for the survivors' new rays ----
-    if (survive) {
-      uint32_t rng = ns.rng, hm;
-      float2 tp;
-      prims_for_ray<COUNT>(S, ns.o, ns.d, rng, tp, hm, cn);
-      if (kMissShortcut && !MULTI && hm == HITMAT_MISS) {  // traceRay.wgsl:12-16 (see shade_body)
-        end_sample_progressive(P, ns.pid, mk3(rc.bg[0], rc.bg[1], rc.bg[2]) * ns.T, (ns.bounce & kAccWritten) != 0);
-        tally++;
-        busy = false;
-      } else {
-        st.q0 = make_float4(ns.o.x, ns.o.y, ns.o.z, __uint_as_float(rng));
-        st.q1 = make_float4(ns.d.x, ns.d.y, ns.d.z, __uint_as_float(ns.pid));
-        st.q2 = make_float4(ns.T.x, ns.T.y, ns.T.z, __int_as_float(ns.bounce));
-        st.tp = tp;
-        st.hitmat = hm;
-      }
-    }
-    // ---- D: rays that entered the root box go to the next queue ----
-    const bool ex = busy && !fresh && (st.hitmat & HITMAT_BVH) != 0u;
-    const uint64_t km = __ballot(ex);
-    if (km) {
-      const uint32_t kept = (uint32_t)__popcll(km);
-      const uint32_t rank = lanes_below(km);
-      const uint32_t b0 = w_cur, n0 = min(kept, w_rend - w_cur);
-      uint32_t b1 = 0xffffffffu;
-      w_cur += n0;
-      if (kept > n0) {  // claim the wave's next region for the rest
-        uint32_t nb = 0;
-        bool full;
-        if (w_rend == 0u) {  // the wave's first region: its quarter of the block's claim
-          if (lane == 0) nb = atomicCAS(&s_region0, kR0Empty, kR0Busy);
-          nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
-          if (nb == kR0Empty) {
-            if (lane == 0) {
-              nb = atomicAdd(&ctl[1].n_rays, region);
-              if (nb + region > P.cap) {  // cannot happen with the host's sizing
-                atomicAdd(&totals[15], 1ull);
-                atomicSub(&ctl[1].n_rays, region);
-                nb = kR0Full;
-              }
-              atomicExch(&s_region0, nb);
-            }
-            nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
-          } else {
-            while (nb == kR0Busy) {
-              __builtin_amdgcn_s_sleep(8);
-              if (lane == 0) nb = atomicAdd(&s_region0, 0u);
-              nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
-            }
-          }
-          full = nb == kR0Full;
-          nb += wv * wregion;
-        } else {
-          if (lane == 0) nb = atomicAdd(&ctl[1].n_rays, wregion);
-          nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
-          full = nb + wregion > P.cap;
-          if (full && lane == 0) {
-            atomicAdd(&totals[15], 1ull);
-            atomicSub(&ctl[1].n_rays, wregion);
-          }
-        }
-        if (!full) {  // (full: what still fitted is written, the rest is dropped and flagged — see shade_body)
-          b1 = nb;
-          w_cur = nb + (kept - n0);
-          w_rend = nb + wregion;
-        }
-      }
-      if (ex) {
-        if (rank < n0 || b1 != 0xffffffffu) {
-          const uint32_t dst = (rank < n0) ? (b0 + rank) : (b1 + (rank - n0));
-          P.out.q0[dst] = st.q0;
-          P.out.q1[dst] = st.q1;
-          P.out.q2[dst] = st.q2;
-          P.hout.tp[dst] = st.tp;
-          P.hout.mat[dst] = st.hitmat;
-        }
-        busy = false;
-      }
-    }
-    if (__ballot(busy) == 0ull && pos == 64u && gnext * 64u >= n) break;  // nothing in flight, nothing left to take
-  }
-  for (int off2 = 32; off2 > 0; off2 >>= 1) tally += __shfl_down(tally, off2, 64);
-  if (lane == 0 && tally) atomicAdd(tally_line(totals, blockIdx.x), tally);
-  __syncthreads();  // the block's claim, if any wave made one, is in s_region0 now
-  if (w_rend == 0u && s_region0 < kR0Full) {  // never needed a region: all of this wave's quarter of the block's claim becomes holes
-    w_cur = s_region0 + wv * wregion;
-    w_rend = w_cur + wregion;
-  }
-  for (uint32_t i = w_cur + (uint32_t)lane; i < w_rend; i += 64u) {
-    reinterpret_cast<uint32_t*>(P.out.q1 + i)[3] = PID_HOLE;
-    P.hout.mat[i] = HITMAT_HOLE;
-  }
-  if (COUNT) reduce_counters(cn, totals, false);
-}
-
+// (Round 5 built two more forms of this body, both bit-exact through the parity suite, neither faster, neither kept — the code is in the history under "Experiment: ...":
+//  * the new rays BINNED BY THE SIGNS OF THEIR DIRECTION before the flush pass (eight waves of a 512-thread block sharing eight lock-free LDS rings): rays of one octant agree
+//    on every axis-aligned quad's facing test, so the pass runs 2.0 quads instead of 3.9 per group at 63 lanes instead of 32 — a quarter of the kernel's vector instructions
+//    gone, and its time unchanged (7.9 against 7.75 ms on configs[1]);
+//  * the body AS A LOOP: a lane keeps its path from bounce to bounce while the new ray needs no tree walk, only rays that entered the root box go through the next queue
+//    (one in twelve on configs[1]: most of the kernel's traffic gone, k_bvh -16 % on dense queues) — and k_shade +7 %, its passes at 45-56 lanes instead of 63.
+//  Together with a probe that ADDS traffic (16 bytes more per kept ray, +12 %: +6-8 % time) they say what the kernel is bound by: neither issue slots nor bytes but the
+//  round trips of a wave's dependent chain at six waves per SIMD.  profiles/r05_shade_bins_ab.txt, r05_shade_loop_ab.txt, NOTES_r05 §3.)
 // The kernel proper, twice: the progressive-mode variants without importance sampling fit 80 VGPRs — 6 waves per SIMD, which this
 // latency-bound kernel turns into throughput (round 3: 5 -> 6 blocks per CU, -8 %) —, the others need up to 96 (5 waves; at 80 they spill).
 template <bool IS, bool SORT, bool COUNT, bool MULTI>
@@ -1231,13 +1062,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) 
                                                                                                 uint32_t* __restrict__ heads, unsigned long long* __restrict__ totals, int first, uint32_t resv) {
   if constexpr (SORT) shade_body<false, COUNT, false>(S, rc, P, ctl, heads, totals, first, resv);
   else shade_body_wave<false, COUNT, false>(S, rc, P, ctl, heads, totals, first, resv);
-}
-
-// ... and the loop form of the 80-VGPR case
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_shade6l(DevScene S, RenderConst rc, Paths P, StepCtl* __restrict__ ctl,
-                                                                                                 uint32_t* __restrict__ heads, unsigned long long* __restrict__ totals, int first, uint32_t resv) {
-  shade_body_loop<false, COUNT, false>(S, rc, P, ctl, heads, totals, first, resv);
 }
 
 // k_tail — a SHORT queue traced to the end in one launch: every lane takes a path and runs ray_color's loop for it (hitScene part 2 on
