@@ -495,6 +495,42 @@ def cpu_baseline(pkg, wl, spp, args):
     return out
 
 
+def js_traversal(wl, n_rays=300000):
+    """north_star's literal CPU baseline — "the reference's single-threaded JS BVH traversal" — does not exist in the reference (its only traversal is WGSL,
+    shaders/hitRay.wgsl:42-110).  This is that WGSL restated in JavaScript (js/hit_scene.mjs: hitScene with hit_sphere / hit_quad / hit_triangle / hit_aabb, f32 by
+    Math.fround; bit-identical hit records to the oracle's, tests/test_js_host.py), timed single-threaded under Node on this box over a bounded sample of rays
+    against the workload's own buffers: half of them leave the camera's neighbourhood towards the scene, half start anywhere in the room in random directions."""
+    node = shutil.which("node") or shutil.which("nodejs")
+    b = wl["buffers"]
+    if not node or len(b.get("bvh", ())) == 0:
+        return None
+    d = tempfile.mkdtemp(prefix="ptmi_jstrav_", dir="/tmp")
+    try:
+        for k in ("spheres", "quads", "triangles", "meshes", "transforms", "materials", "bvh"):
+            np.ascontiguousarray(b[k]).tofile(os.path.join(d, "w_%s.bin" % k))
+        rng = np.random.default_rng(17)
+        h = n_rays // 2
+        o = rng.uniform(-0.3, 0.3, (h, 3)) + np.array([0, -0.1, 2.4])
+        dr = rng.uniform(-1.0, 1.0, (h, 3)) * np.array([1.2, 1.0, 0.9]) - o
+        dr /= np.linalg.norm(dr, axis=1, keepdims=True)
+        di = rng.normal(0, 1, (h, 3))
+        di /= np.linalg.norm(di, axis=1, keepdims=True)
+        rays = np.concatenate([np.concatenate([o, dr], 1), np.concatenate([rng.uniform(-0.95, 0.95, (h, 3)), di], 1)]).astype(np.float32)
+        rays.tofile(os.path.join(d, "rays.f32"))
+        r = subprocess.run([node, "--max-old-space-size=8192", os.path.join(ROOT, "webgpu-path-tracer_amd", "js", "traverse_time.mjs"), d, "w", os.path.join(d, "rays.f32"), "", str(wl["stack"])],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        if r.returncode != 0:
+            return {"error": r.stderr[-300:]}
+        js = json.loads(r.stdout)
+        return {"value": js["mrays_s"], "unit": "Mrays/s", "cores": 1, "rays": js["rays"], "node_visits_per_ray": js["node_visits"] / max(1, js["rays"]), "node": js["node"],
+                "sample": "hitScene in single-threaded JavaScript (js/hit_scene.mjs) on %d synthetic rays against the workload's buffers, stack %d" % (js["rays"], wl["stack"]),
+                "reference": "shaders/hitRay.wgsl:1-113 restated; the reference itself has no CPU traversal"}
+    except Exception as e:
+        return {"error": str(e)[:200]}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def js_bvh_build(native):
     """The reference's one CPU loop — the median-split BVH build (lib/BVH/bvhNode.js:28-73) — as single-threaded JavaScript under
     Node on this box (js/bvh_time.mjs: the shipped restatement, byte-identical output to the reference's, tests/test_host_buffers.py)."""
@@ -872,6 +908,7 @@ def worker(args):
             if args.cpu_seconds > 0:
                 wl3["setup"]["bvh_build_js_single_thread"] = js_bvh_build(wl3["native"])
                 wl3["setup"]["obj_parse"] = obj_parse_times(wl3["buffers"]["triangles"].size // 24)
+                d3["cpu_js_traversal"] = js_traversal(wl3)  # north_star's "single-threaded JS BVH traversal", on its target scene
             d3["setup_ms"] = wl3["setup"]
             # ... and the same scene from the reference's OTHER builder (lib/BVH/bvhNode.js:108-283, which its renderer never calls), built on the GPU: an opt-in
             # (--bvh sah), so informational here — the configuration's own figure above is on the median tree the reference renders with
@@ -894,6 +931,7 @@ def worker(args):
         out["setup_ms"] = setup[args.workload]
         if args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(pkg, wl, spp, args)
+            out["cpu_baseline"]["js_traversal"] = js_traversal(wl)
             if extra_c3 and out["configs"][0]["setup_ms"].get("bvh_build_js_single_thread"):
                 out["cpu_baseline"]["bvh_build_js_ms"] = out["configs"][0]["setup_ms"]["bvh_build_js_single_thread"]
             elif args.workload != "c2":

@@ -78,6 +78,38 @@ def test_js_camera_interaction_matches_reference_js():
 
 
 @needs_node
+@pytest.mark.parametrize("name,stack", [("c1", 20), ("c2", 20), ("c2", 3)])
+def test_js_hit_scene_equals_the_oracle(tmp_path, pkg, oracle, name, stack):
+    """js/hit_scene.mjs — hitScene (hitRay.wgsl:1-113, common.wgsl:29-73,148-256) restated in JavaScript, bench.py's `cpu_baseline.js_traversal` — returns the oracle's
+    hit records bit for bit on the reference's own buffers (goldens), incl. the Q7 abort at a stack of 3: a second restatement of the same WGSL, in another language, with f32
+    made from f64 by Math.fround, agrees with the C++ one."""
+    b = pkg.scenes.golden_buffers(name)
+    rng = np.random.default_rng(5)
+    o = rng.uniform(-0.3, 0.3, (4000, 3)) + np.array([0, -0.1, 2.4])
+    d = rng.uniform(-1.0, 1.0, (4000, 3)) * np.array([1.2, 1.0, 0.9]) - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([np.concatenate([o, d], 1), np.concatenate([rng.uniform(-0.95, 0.95, (4000, 3)), rng.normal(0, 1, (4000, 3))], 1)]).astype(np.float32)
+    rays[-3:, 3:] = [[0, 1, 0], [1, 0, 0], [0, 0, -1]]  # axis-aligned: infinite inverse directions in hit_aabb
+    rays.tofile(tmp_path / "rays.f32")
+    out = json.loads(_run([node, os.path.join(JS, "traverse_time.mjs"), os.path.join(ROOT, "tests", "golden"), name, str(tmp_path / "rays.f32"), str(tmp_path / "hits.bin"), str(stack)]))
+    want, _, st = oracle.hit_scene(b, rays, None, stack_size=stack)
+    n = rays.shape[0]
+    raw = np.fromfile(tmp_path / "hits.bin", np.uint8)
+    rec = raw[: 36 * n].view(np.float32).reshape(n, 9)
+    mat = raw[36 * n :].view(np.int32)
+    assert out["rays"] == n and out["node_visits"] == st["node_visits"] and out["tri_tests"] == st["tri_tests"]
+    assert np.array_equal(rec[:, 0] == 1, want["hit"] == 1)
+    m = want["hit"] == 1
+    assert m.sum() > 1000
+    assert_same_bits(rec[m, 1], want["t"][m], name + ".t")
+    assert_same_bits(rec[m, 2:5], want["p"][m], name + ".p")
+    assert_same_bits(rec[m, 5:8], want["normal"][m], name + ".normal")
+    assert np.array_equal(rec[m, 8] == 1, want["front_face"][m] == 1)
+    mats = b["materials"].reshape(-1, 16)
+    assert_same_bits(mats[mat[m]], want["material"][m], name + ".material")
+
+
+@needs_node
 def test_wgsl_header_constants_become_params():
     src = "import {paramsFromWGSL} from './webgpu_node.mjs'; console.log(JSON.stringify(paramsFromWGSL('const NUM_SAMPLES = 4;\\nconst MAX_BOUNCES = 8;\\nconst STRATIFY = true;\\nconst IMPORTANCE_SAMPLING = false;\\nconst STACK_SIZE = 24;\\n let background_color = vec3f(0.5, 0, 1);')))"
     f = os.path.join(JS, "_t.mjs")

@@ -43,6 +43,9 @@ if S:
         "—" if w not in S else "**%.0f** / %.1f / %s / %.0f (%d, %d)" % (S[w]["value"], S[w]["roofline"]["work_per_ray"]["node_visits"], f(S[w]["roofline"]["kernels"]["k_bvh"]["ms_per_step"], 2 if S[w]["roofline"]["kernels"]["k_bvh"]["ms_per_step"] < 100 else 0),
                                                         S[w]["setup_ms"]["build_scene_bvh_sah_device_ms"], S[w]["setup_ms"]["sah_tree"]["nodes"], S[w]["setup_ms"]["sah_tree"]["depth"]) for w in cols) + " |")
 rows.append("| CPU oracle, 16 threads / 1 thread (Mrays/s) | " + " | ".join("%.1f / %.1f" % (D[w]["cpu_baseline"]["value"], D[w]["cpu_baseline"]["single_thread"]["value"]) for w in cols) + " |")
+if any((D[w]["cpu_baseline"].get("js_traversal") or {}).get("value") for w in cols):
+    rows.append("| `hitScene` restated in single-threaded JavaScript under Node (`js/hit_scene.mjs`; Mrays/s, synthetic rays) | " + " | ".join(
+        ("%.2f" % D[w]["cpu_baseline"]["js_traversal"]["value"]) if (D[w]["cpu_baseline"].get("js_traversal") or {}).get("value") else "—" for w in cols) + " |")
 rows.append("| vs. 33.5 Mpaths/s (`benchmarks.txt:18-20`): paths / rays | " + " | ".join("%.0f× / %.0f×" % (D[w]["config"]["mpaths_per_s"] / 33.5, D[w]["value"] / 33.5) for w in cols) + " |")
 table = "\n".join("  " + r for r in rows)
 p = os.path.join(ROOT, "DESIGN.md")
