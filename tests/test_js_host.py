@@ -110,6 +110,29 @@ def test_js_hit_scene_equals_the_oracle(tmp_path, pkg, oracle, name, stack):
 
 
 @needs_node
+def test_obj_number_quirks_native_parser_vs_javascript(tmp_path, pkg):
+    """lib/primitives/objReader.js:10-68 turns every token into a number with JavaScript's Number(): hex / binary / octal literals, 'Infinity', signs, exponents without
+    digits, separators ... The native parser (ptmi_obj_parse) must agree with JavaScript ITSELF (js/lib/scene.mjs under Node — the reader whose output equals the
+    reference's on its own assets) on a list of such tokens and on random strings over the characters numbers are made of."""
+    toks = ["1", "-1", "+1", "1.", "1.5e3", ".5", "+.5", "-.5e-2", "1e", "1e+", "e5", "0x10", "0X1f", "0b11", "0o17", "Infinity", "-Infinity", "+Infinity", "infinity", "inf", "NaN", "nan",
+            "1e400", "-1e400", "1e-400", "1_0", "1,5", "0x", "0x1.8p3", "1f", "1d", "1e5.5", "--1", "+-1", "1.2.3", ".", "-.", "+", "-", "00012", "-0", "0.0000001",
+            "123456789012345678901234567890", "4.9e-324", "1.7976931348623157e308", "0x1fffffffffffff", "1e3x", "0.1", "3.4028235e38", "3.4028236e38", "1e-46", "7.0064923216240854e-46"]
+    rng = np.random.default_rng(3)
+    alphabet = list("0123456789.+-eExXbBoO_aAfFInity")
+    toks += ["".join(rng.choice(alphabet, rng.integers(1, 9))) for _ in range(448)]
+    lines = ["v %s 0 0" % t for t in toks] + ["vn 0 0 1"] + ["f %d/1/1 %d/1/1 %d/1/1" % (i + 1, i + 2, i + 3) for i in range(0, len(toks) - 2, 3)]
+    text = "\n".join(lines) + "\n"
+    (tmp_path / "t.obj").write_text(text)
+    js = _run([node, "--input-type=module", "-e", "import fs from 'fs'; import {ObjReader} from '%s/lib/scene.mjs'; const r = ObjReader.parse(fs.readFileSync('%s', 'utf8')); "
+               "console.log(Buffer.from(r.vertices.buffer, r.vertices.byteOffset, r.vertices.byteLength).toString('base64'))" % (JS, tmp_path / "t.obj")])
+    want = np.frombuffer(base64.b64decode(js.strip()), np.float32)
+    got = np.asarray(pkg.ptmi.NativeHost().parse_obj(text)["vertices"]).reshape(-1)
+    assert got.size == want.size == 3 * 3 * (len(toks) // 3)
+    bad = [toks[k // 3] for k in range(0, got.size, 3) if not ((np.isnan(got[k]) and np.isnan(want[k])) or got[k].view(np.uint32) == want[k].view(np.uint32))]
+    assert not bad, bad[:10]
+
+
+@needs_node
 def test_wgsl_header_constants_become_params():
     src = "import {paramsFromWGSL} from './webgpu_node.mjs'; console.log(JSON.stringify(paramsFromWGSL('const NUM_SAMPLES = 4;\\nconst MAX_BOUNCES = 8;\\nconst STRATIFY = true;\\nconst IMPORTANCE_SAMPLING = false;\\nconst STACK_SIZE = 24;\\n let background_color = vec3f(0.5, 0, 1);')))"
     f = os.path.join(JS, "_t.mjs")
