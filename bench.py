@@ -360,6 +360,11 @@ def roofline_of(tab, dom, timed_ms_per_launch, timed_launches, gather_records_pe
                              "all-unclassified-at-4 upper bound, rocprof's own VALUBusy (counts every instruction as >= 4 cycles: a kernel of 2-cycle instructions reads "
                              "2x too busy, profiles/r04_valu_busy_calib.json) and the lane-weighted fraction",
                   "peak_definition": "1024 SIMDs x 2.4 GHz / (average issue cycles per wave64 instruction of this kernel = %.2f)" % (e.get("avg_cycles_per_valu_instr") or 0.0)})
+    if r.get("bound") == "valu_issue" and r.get("kernel") == "k_shade":
+        r["bound_probes"] = ("round 5 (profiles/NOTES_r05.md §3): a quarter of this kernel's vector instructions removed three bit-exact ways (direction-binned flush passes, "
+                             "hit_quad for axis-aligned quads, a quad's Lambertian frame from a table) changes its time by 0 +- 2 %; 16 more bytes per kept ray (+12 % traffic) cost "
+                             "6-8 %; most of its traffic removed (paths kept in their lanes) with a fifth more instructions costs 7 %.  `frac` is the busiest resource, not a "
+                             "binding bound: the kernel waits on the round trips of each wave's dependent chain at six waves per SIMD")
     if max(vf or 0.0, hf or 0.0, gf or 0.0) < 0.5:
         r["bound_note"] = "no resource is busy half the time: the kernel waits on memory latency (wave_wait_frac %.2f)" % (e.get("wave_wait_frac") or 0.0)
     r["valu_busy_frac_at_2p4_ghz"], r["fabric_frac_of_hbm_peak"], r["l1_gather_frac"] = vf, hf, gf
