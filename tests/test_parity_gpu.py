@@ -553,7 +553,7 @@ def _random_scene(pkg, seed):
     return sc, r
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PTMI_RANDOM_SCENES", "16"))))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PTMI_RANDOM_SEED0", "0")), int(__import__("os").environ.get("PTMI_RANDOM_SEED0", "0")) + int(__import__("os").environ.get("PTMI_RANDOM_SCENES", "16"))))  # (soaks: PTMI_RANDOM_SCENES=n [PTMI_RANDOM_SEED0=k])
 def test_random_scenes_bit_exact(ctx, pkg, oracle, seed):
     sc, r = _random_scene(pkg, seed)
     b = sc.buffers(native=pkg.ptmi.NativeHost())
