@@ -776,9 +776,10 @@ def test_auto_batch_shrinks_when_memory_is_short(pkg, hooks, oracle, monkeypatch
     assert_same_bits(got.reshape(-1, 4)[256 * 100:256 * 100 + 512], want.reshape(-1, 4)[256 * 100:256 * 100 + 512], "two rows of the 512-frame image")
 
 
-def test_placement_search_is_invisible(pkg, monkeypatch):
-    """A context that allocates queue arrays for >= 16 Mi slots tries up to PTMI_PLACEMENT_TRIES sets and keeps the one the memory system
-    serves fastest (ptmi.hip, ensure_paths): whichever set it ends up with, the image and the counters are the same."""
+def test_placement_search_is_invisible(pkg, monkeypatch, pipeline):
+    """A context whose batch needs queue arrays of >= 16 Mi slots (and is not handed to k_tail whole) tries up to PTMI_PLACEMENT_TRIES sets of them, timing the batch's own
+    k_generate and first two steps — run dry — on each, and keeps the fastest (ptmi.hip, placement_search): whichever set it ends up with, and however often the batch's
+    beginning was traced for the stopwatch, the image, the counters and the launch statistics are those of a context that never searched."""
     b = pkg.scenes.golden_buffers("c2")
     view = cornell_view(pkg)
     results = []
@@ -786,12 +787,16 @@ def test_placement_search_is_invisible(pkg, monkeypatch):
         monkeypatch.setenv("PTMI_PLACEMENT_TRIES", tries)
         with pkg.Context(0) as ctx:
             ctx.upload_scene(b)
-            ctx.set_params(max_bounces=4, frames_in_flight=8)
+            ctx.set_params(max_bounces=4, frames_in_flight=16)
+            ctx.set_counters(True)
             ctx.resize(1920, 1080)
-            ctx.render(view, 1, 8)  # 16.6 M paths: 20.8 M slots per queue array
-            results.append((ctx.read_framebuffer(), ctx.stats()["rays"]))
+            ctx.render(view, 1, 16)  # 33.2 M paths: 41.5 M slots per queue array, more than k_tail takes whole (24 Mi)
+            fb = ctx.read_framebuffer()
+            st = ctx.stats()
+            results.append((fb, {k: st[k] for k in ("rays", "paths", "frames", "node_visits", "tri_tests", "quad_tests", "generate_launches", "shade_launches", "intersect_launches", "accumulate_launches")}, st["placement_sets"]))
     assert_same_bits(results[0][0], results[1][0], "placement search off / on")
     assert results[0][1] == results[1][1]
+    assert results[0][2] <= 1 and (results[1][2] >= 2 or pipeline == "tail")  # (k_tail takes that pipeline's batch whole: nothing to search for)
 
 
 def test_failed_triangle_reupload_keeps_the_old_scene(pkg, hooks, oracle, monkeypatch):

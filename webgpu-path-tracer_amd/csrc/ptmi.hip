@@ -198,6 +198,7 @@ struct ptmi_ctx {
   uint32_t last_frame = 0;
   float last_view[16];
   int static_streak = 0;  // consecutive ptmi_render_frame calls with the same view, frame numbers +1, no reset
+  bool placement_pending = false;  // ensure_paths has just (re)allocated the queue arrays of a batch worth a placement search: render_batch runs it
   bool interactive = false;  // inside ptmi_render_frame: its batches grow 8 -> 64 frames while the user watches — no placement search (40 ms each)
   int ahead_batch = 8;
 
@@ -606,75 +607,15 @@ int ensure_paths(ptmi_ctx* c, size_t npaths, int n_ctl, bool need_pixsum) {
     c->path_cap = npaths;
     c->slot_cap = slots;
     c->pixsum_alloc = false;
-    // Where the driver puts the queue arrays decides how often their streams meet in the same HBM channels: k_shade runs up to 12 % slower
-    // in some contexts than in others, for their whole life (DESIGN.md §4 "placement").  So for batches worth the trouble (>= 16 Mi slots — smaller ones belong to k_tail or last microseconds —, not from ptmi_render_frame): allocate
-    // up to PTMI_PLACEMENT_TRIES (4) sets, time the step's access pattern on each (k_placement_probe, ~30 ms per set), keep the fastest.  Two sets
-    // exist at a time; an extra allocation that fails just ends the search.
+    // Batches worth a placement search (placement_search below): >= 16 Mi slots — smaller ones belong to k_tail or last microseconds —, not from ptmi_render_frame,
+    // not where shards share the GPU or the board could not hold two sets.
     const int tries = c->tun.placement_tries;
-    // (sets of more than 32 GB are taken as they come: allocating and releasing 76 GB three more times costs seconds, and the long launches of
-    // such batches showed no placement effect — configs[2] at 256 spp)
     c->stats.placement_sets = 0;
     c->stats.placement_ms = 0.0;
-    // (not when shards of this context share the GPU — their probes would time each other —, nor when the board could not hold a second set)
     size_t mem_free = 0, mem_total = 0;
     if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = 0, (void)hipGetLastError();
-    if (tries > 1 && !c->interactive && !c->shares_device && slots >= ((size_t)1 << 24) && slots * 120 <= ((size_t)32 << 30) && mem_free >= slots * 120 * 2) {
-      const auto t_search = std::chrono::steady_clock::now();
-      struct Events {  // destroyed on every way out of the search
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        ~Events() {
-          if (e0) (void)hipEventDestroy(e0);
-          if (e1) (void)hipEventDestroy(e1);
-        }
-      } ev;
-      HIP_TRY(c, hipEventCreate(&ev.e0));
-      HIP_TRY(c, hipEventCreate(&ev.e1));
-      const hipEvent_t e0 = ev.e0, e1 = ev.e1;
-      const uint32_t pn = (uint32_t)std::min<size_t>(slots, (size_t)1 << 26);
-      auto score = [&](float* ms) -> hipError_t {
-        float total = 0.0f;
-        for (int rep = 0; rep < 3; rep++) {  // (the first pass pages the buffers in: not counted)
-          for (int dir = 0; dir < 2; dir++) {
-            Paths P = paths_of(c, dir, false);
-            if (hipError_t e = hipEventRecord(e0, c->stream)) return e;
-            hipLaunchKernelGGL(k_placement_probe, dim3((unsigned)c->num_cus * 8), dim3(kBlock), 0, c->stream, P, pn);
-            if (hipError_t e = hipEventRecord(e1, c->stream)) return e;
-            if (hipError_t e = hipEventSynchronize(e1)) return e;
-            float t = 0.0f;
-            if (hipError_t e = hipEventElapsedTime(&t, e0, e1)) return e;
-            if (rep) total += t;
-          }
-        }
-        *ms = total;
-        return hipSuccess;
-      };
-      float best = 0.0f;
-      HIP_TRY(c, score(&best));
-      c->stats.placement_sets = 1;
-      if (c->tun.debug_placement) fprintf(stderr, "ptmi placement: set 0 %.3f ms\n", best);
-      DBuf* mine[10] = {&c->d_q0[0], &c->d_q0[1], &c->d_q1[0], &c->d_q1[1], &c->d_q2[0], &c->d_q2[1], &c->d_tp[0], &c->d_tp[1], &c->d_hm[0], &c->d_hm[1]};
-      const size_t width[10] = {16, 16, 16, 16, 16, 16, 8, 8, 4, 4};
-      for (int t = 1; t < tries; t++) {
-        DBuf cand[10];
-        bool ok = true;
-        for (int k = 0; k < 10 && ok; k++) ok = cand[k].ensure(slots * width[k]) == hipSuccess;
-        float ms = 0.0f;
-        if (ok) {
-          for (int k = 0; k < 10; k++) std::swap(*mine[k], cand[k]);  // (cand now holds the best set so far)
-          ok = score(&ms) == hipSuccess;
-          if (ok) c->stats.placement_sets++;
-          if (c->tun.debug_placement) fprintf(stderr, "ptmi placement: set %d %.3f ms\n", t, ms);
-          if (!ok || ms >= best) {
-            for (int k = 0; k < 10; k++) std::swap(*mine[k], cand[k]);  // keep the old one
-          } else {
-            best = ms;
-          }
-        }
-        for (int k = 0; k < 10; k++) cand[k].release();
-        if (!ok) break;
-      }
-      c->stats.placement_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_search).count();
-    }
+    // (the search itself runs in render_batch, on the batch that asked for these buffers: placement_search)
+    c->placement_pending = tries > 1 && !c->interactive && !c->shares_device && slots >= ((size_t)1 << 24) && slots * 120 <= ((size_t)32 << 30) && mem_free >= slots * 120 * 2;
   }
   if (need_pixsum && !c->pixsum_alloc) {
     HIP_TRY(c, c->d_pixsum.ensure(c->path_cap * 16));
@@ -873,8 +814,81 @@ void launch_shade(ptmi_ctx* c, uint32_t sgrid, const RenderConst& rc, const Path
   else hipLaunchKernelGGL((k_shade<IS, SO, CN, MU>), dim3(sgrid), dim3(kBlock), 0, c->stream, c->S, rc, P, ctl, c->d_heads.as<uint32_t>(), tot, first, resv);
 }
 
-// `fold` = how many of the batch's leading frames are added to the framebuffer now (-1 = all of them)
-int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames, int reset_first, int fold = -1) {
+// Placement search (DESIGN.md §3 "placement"): where the driver puts the queue arrays decides how often their streams meet in the same HBM channels — k_shade runs up to 12 %
+// slower in some contexts than in others, for their whole life.  For batches worth the trouble the context therefore tries up to PTMI_PLACEMENT_TRIES (4) sets of queue
+// arrays, two alive at a time, and keeps the fastest.  Round 5: what is timed on each set is THE BATCH ITSELF — its k_generate and its first two steps, run dry (`dry` =
+// render_batch(..., dry_steps = 2): no accumulation, no counters, no statistics; the real run that follows starts from scratch anyway) — instead of a synthetic kernel that
+// imitated a step's access pattern and predicted the kernels' times poorly (profiles/r05_placement_tries.txt).  The first dry run of a set pages it in and is not counted.
+int placement_search(ptmi_ctx* c, const std::function<int()>& dry) {
+  const auto t_search = std::chrono::steady_clock::now();
+  const size_t slots = c->slot_cap;
+  struct Events {  // destroyed on every way out of the search
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Events() {
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+    }
+  } ev;
+  HIP_TRY(c, hipEventCreate(&ev.e0));
+  HIP_TRY(c, hipEventCreate(&ev.e1));
+  struct Restore {  // the dry runs leave no trace in what the caller can observe
+    ptmi_ctx* c;
+    ptmi_stats stats;
+    int timing;
+    bool counters;
+    ~Restore() {
+      c->stats = stats;
+      c->timing = timing;
+      c->counters = counters;
+      c->batch_enqueued = false;
+    }
+  } restore{c, c->stats, c->timing, c->counters};
+  c->timing = 0;
+  c->counters = false;
+  auto score = [&](float* ms) -> int {
+    if (int r = dry()) return r;
+    HIP_TRY(c, hipEventRecord(ev.e0, c->stream));
+    if (int r = dry()) return r;
+    HIP_TRY(c, hipEventRecord(ev.e1, c->stream));
+    HIP_TRY(c, hipEventSynchronize(ev.e1));
+    HIP_TRY(c, hipEventElapsedTime(ms, ev.e0, ev.e1));
+    return PTMI_OK;
+  };
+  float best = 0.0f;
+  if (int r = score(&best)) return r;
+  uint64_t sets = 1;
+  if (c->tun.debug_placement) fprintf(stderr, "ptmi placement: set 0 %.3f ms\n", best);
+  DBuf* mine[10] = {&c->d_q0[0], &c->d_q0[1], &c->d_q1[0], &c->d_q1[1], &c->d_q2[0], &c->d_q2[1], &c->d_tp[0], &c->d_tp[1], &c->d_hm[0], &c->d_hm[1]};
+  const size_t width[10] = {16, 16, 16, 16, 16, 16, 8, 8, 4, 4};
+  int rc_out = PTMI_OK;
+  for (int t = 1; t < c->tun.placement_tries; t++) {
+    DBuf cand[10];
+    bool ok = true;
+    for (int k = 0; k < 10 && ok; k++) ok = cand[k].ensure(slots * width[k]) == hipSuccess;  // (an extra allocation that fails just ends the search)
+    float ms = 0.0f;
+    if (ok) {
+      for (int k = 0; k < 10; k++) std::swap(*mine[k], cand[k]);  // (cand now holds the best set so far)
+      rc_out = score(&ms);
+      ok = rc_out == PTMI_OK;
+      if (ok) sets++;
+      if (c->tun.debug_placement) fprintf(stderr, "ptmi placement: set %d %.3f ms\n", t, ms);
+      if (!ok || ms >= best) {
+        for (int k = 0; k < 10; k++) std::swap(*mine[k], cand[k]);  // keep the old one
+      } else {
+        best = ms;
+      }
+    }
+    if (!ok) (void)hipStreamSynchronize(c->stream);  // nothing may still run on a set that is about to go
+    for (int k = 0; k < 10; k++) cand[k].release();
+    if (!ok) break;
+  }
+  restore.stats.placement_sets = sets;
+  restore.stats.placement_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_search).count();
+  return rc_out;
+}
+
+// `fold` = how many of the batch's leading frames are added to the framebuffer now (-1 = all of them); dry_steps > 0: placement_search's timing run
+int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames, int reset_first, int fold = -1, int dry_steps = 0) {
   const ptmi_params& p = c->prm;
   c->ahead.valid = false;  // the path buffers are about to be overwritten
   RenderConst rc{};
@@ -974,6 +988,13 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   const uint32_t tail_limit_first = (uint32_t)(tail_env >= 0 ? tail_env : shallow ? kTailLimitFirstShallow : deep ? kTailLimitFirstDeep : kTailLimitFirst),
                  tail_limit_later = (uint32_t)(tail_env >= 0 ? tail_env : shallow ? kTailLimitLaterShallow : kTailLimitLater);
 
+  if (dry_steps == 0 && c->placement_pending) {
+    c->placement_pending = false;
+    if (total > tail_limit_first) {  // (a batch that k_tail takes whole reads its queue once: nothing to search for)
+      int r = placement_search(c, [&]() { return render_batch(c, view16, frame0, n_frames, reset_first, fold, 2); });
+      if (r) return r;
+    }
+  }
   ScopedSpan whole(c, T_RENDER);
   c->batch_enqueued = true;  // from here on a failure leaves a partly traced batch behind: never retried
   hipLaunchKernelGGL(k_init_ctl, dim3((unsigned)((n_steps + 2 + 63) / 64)), dim3(64), 0, c->stream, ctl, n_steps + 2, resv);  // n_rays = the carry prefix (0 for step 0)
@@ -987,7 +1008,8 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
     c->stats.generate_launches++;
   }
   bool drained = false;
-  for (int s = 0; s < n_steps; s++) {
+  const int run_steps = dry_steps > 0 ? std::min(n_steps, dry_steps) : n_steps;
+  for (int s = 0; s < run_steps; s++) {
     // With the reference's MAX_BOUNCES = 100 nearly all steps run on an empty queue (Russian roulette ends paths after
     // a dozen bounces): from step 12 on, look at the queue length every 8 steps and stop enqueuing once it is empty.
     if (s >= 12 && (s & 7) == 4) {
@@ -1045,6 +1067,7 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
     c->stats.intersect_launches++;
     c->stats.shade_launches++;
   }
+  if (dry_steps > 0) return PTMI_OK;
   if (carry && !drained && n_steps > 0) {
     // paths that were carried over lag behind the step count: whatever the last k_shade left in the queue (and what the last k_bvh carried) is
     // traced to its end by one k_tail launch — a few thousand paths at most

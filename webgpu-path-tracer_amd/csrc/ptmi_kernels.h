@@ -1399,24 +1399,6 @@ struct HitOut {
   float material[16];
 };
 
-// Placement probe (ensure_paths): moves the five fields of the first n slots of `in` to `out` the way a step does — read in lockstep by
-// slot, written densely for five survivors out of eight — so that two sets of queue buffers can be compared by how fast the memory system
-// serves the pattern (DESIGN.md §4 "placement").  The bytes moved are whatever the fresh buffers hold.
-__global__ __launch_bounds__(kBlock) void k_placement_probe(Paths P, uint32_t n) {
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const float4 a = P.in.q0[i], b = P.in.q1[i], c = P.in.q2[i];
-    const float2 t = P.hin.tp[i];
-    const uint32_t m = P.hin.mat[i];
-    if ((i & 7u) < 5u) {
-      const uint32_t j = 5u * (i >> 3) + (i & 7u);
-      P.out.q0[j] = a;
-      P.out.q1[j] = b;
-      P.out.q2[j] = c;
-      P.hout.tp[j] = t;
-      P.hout.mat[j] = m;
-    }
-  }
-}
 __global__ __launch_bounds__(kBlock) void k_resolve_hits(DevScene S, Paths P, uint32_t n, HitOut* __restrict__ out) {
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
