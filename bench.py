@@ -231,7 +231,8 @@ def pmc_passes(args, workload, log):
                                                   "--frames-in-flight", str(args.frames_in_flight), "--bvh", args.bvh, "--stack-size", str(args.stack_size), "--tris", str(args.tris),
                                                   "--spp", str(args.spp if workload == args.workload else 0)]
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=args.pmc_timeout)
+            # (PTMI_PLACEMENT_TRIES=1: no placement search under the profiler — its dry runs are launches of the very kernels being counted)
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", PTMI_PLACEMENT_TRIES="1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=args.pmc_timeout)
         except subprocess.TimeoutExpired:
             shutil.rmtree(d, ignore_errors=True)
             return None, "rocprofv3 pass '%s' timed out" % tag

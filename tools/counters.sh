@@ -5,6 +5,7 @@
 #   tools/counters.sh ta     <tag> <workload> <spp> [bench args]   texture addresser / L1 / texture data: is k_bvh bound by its 16-byte record gathers?
 #   tools/counters.sh tabusy                                       texture-addresser busy fraction per kernel, all four workloads -> gpurun_out/ta_busy.json
 # The environment (PTMI_LIB for an A/B build, PTMI_* tuning variables) is inherited by the bench processes.
+export PTMI_PLACEMENT_TRIES=${PTMI_PLACEMENT_TRIES:-1}  # no placement search under the profiler: its dry runs are launches of the kernels being profiled
 kind=$1; shift
 bench_args() { echo "--workload $1 --spp $2 --steps 1 --warmup 0 --cpu-seconds 0 --pmc off --extra-configs off"; }
 case $kind in

@@ -2,6 +2,7 @@
 # usage: tools/pmc.sh <tag> "<counters>" <bench args...>   — rocprofv3 --pmc over `python3 bench.py <args>`, per-kernel sums in gpurun_out/pmc_<tag>.json.
 # The counter list may be of any length: tools/pmc_split.py cuts it into passes that fit the blocks' counter slots (an over-subscribed pass makes
 # rocprofv3 abort at the first HIP call — round 3 lost five leases to that), one rocprofv3 run per pass, results merged per kernel.
+export PTMI_PLACEMENT_TRIES=${PTMI_PLACEMENT_TRIES:-1}  # no placement search under the profiler: its dry runs are launches of the kernels being profiled
 tag=$1; ctrs=$2; shift 2
 export TMPDIR=/tmp; mkdir -p gpurun_out
 n=0; dirs=""

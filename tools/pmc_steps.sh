@@ -2,6 +2,7 @@
 # usage: tools/pmc_steps.sh <tag> <kernel substring> "<counters>" [script.py] <args...> — rocprofv3 --pmc, counters PER DISPATCH of one kernel (the steps of a
 # render: launch k of a step is bounce k), first 16 (PMC_ROWS) dispatches, in gpurun_out/pmcsteps_<tag>.txt.  Any number of counters: tools/pmc_split.py
 # cuts the list into passes that fit the hardware's counter slots (one rocprofv3 run each, merged by dispatch order).
+export PTMI_PLACEMENT_TRIES=${PTMI_PLACEMENT_TRIES:-1}  # no placement search under the profiler: its dry runs are launches of the kernels being profiled
 tag=$1; kern=$2; ctrs=$3; shift 3
 prog="bench.py"; if [[ "$1" == *.py ]]; then prog=$1; shift; fi   # (another script instead of bench.py: name it first)
 export TMPDIR=/tmp; mkdir -p gpurun_out

@@ -22,12 +22,14 @@ timeout -k 10 600 python bench.py --workload c3 --bvh sah --steps 2 --cpu-second
 timeout -k 10 600 python bench.py --workload c4 --bvh sah --steps 1 --cpu-seconds 0 --pmc-timeout 400 > $R/bench_c4_sah.json 2> $R/bench_c4_sah.err || exit 1
 timeout -k 10 600 python bench.py --workload c5 --bvh sah --width 3840 --height 2160 --spp 128 --steps 1 --cpu-seconds 0 --pmc-timeout 400 > $R/bench_c5_sah.json 2> $R/bench_c5_sah.err || exit 1
 # rocprofv3 kernel stats of the bench command itself (its own --pmc child passes off: one profiler at a time)
+export PTMI_PLACEMENT_TRIES=1  # (the placement search's dry runs are launches of the same kernels: kept out of the averages)
 for w in c2 c3 c4 c5; do
   rm -rf /tmp/ks_$w
   x=""; [ $w = c4 ] && x="--spp 128"; [ $w = c5 ] && x="--width 3840 --height 2160 --spp 64"
   (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$w -o run -- python3 $root/bench.py --workload $w $x --steps 3 --warmup 1 --cpu-seconds 0 --pmc off --extra-configs off > $root/$R/ks_$w.log 2>&1) || exit 1
   cp $(find /tmp/ks_$w -name '*kernel_stats.csv' | head -1) $R/kernel_stats_$w.csv || exit 1
 done
+unset PTMI_PLACEMENT_TRIES
 fi
 if [ "$1" != quick ]; then
 [ -x tools/valu_peak ] && timeout -k 10 300 tools/valu_peak > $R/valu_peak.json 2> $R/valu_peak.err

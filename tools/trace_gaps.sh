@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage: tools/trace_gaps.sh <tag> <python script and args...> — busy vs idle time of the GPU between the first and last kernel
+export PTMI_PLACEMENT_TRIES=${PTMI_PLACEMENT_TRIES:-1}  # no placement search under the profiler: its dry runs are launches of the kernels being profiled
 tag=$1; shift
 out=/tmp/kg_$tag; rm -rf $out; export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out -o run -- python3 "$@" > /tmp/kg_$tag.log 2>&1

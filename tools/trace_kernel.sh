@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage: tools/trace_kernel.sh <tag> <kernel substring> [script.py] <args...>   (bench.py when no script is named) — per-launch durations (ms) of one kernel, timed pass only
+export PTMI_PLACEMENT_TRIES=${PTMI_PLACEMENT_TRIES:-1}  # no placement search under the profiler: its dry runs are launches of the kernels being profiled
 tag=$1; kern=$2; shift 2
 out=/tmp/kt_$tag; rm -rf $out; export TMPDIR=/tmp
 prog="bench.py"; if [[ "$1" == *.py ]]; then prog=$1; shift; fi

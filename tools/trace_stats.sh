@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage: tools/trace_stats.sh <tag> <python script and args...> — rocprofv3 kernel stats (calls, total, average) of any script
+export PTMI_PLACEMENT_TRIES=${PTMI_PLACEMENT_TRIES:-1}  # no placement search under the profiler: its dry runs are launches of the kernels being profiled
 tag=$1; shift
 out=/tmp/ks_$tag; rm -rf $out; export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o run -- python3 "$@" > /tmp/ks_$tag.log 2>&1

@@ -136,7 +136,7 @@ struct Tuning {
   int tail_limit = -1;         // PTMI_TAIL_LIMIT: k_tail takes queues of at most this many slots (-1 = kTailLimitFirst / kTailLimitLater, 0 = never)
   bool render_ahead = true;    // PTMI_RENDER_AHEAD=0
   int path_budget_log2 = 29;   // PTMI_PATH_BUDGET_LOG2: paths per wavefront pass with frames_in_flight = auto
-  int placement_tries = 4;     // PTMI_PLACEMENT_TRIES
+  int placement_tries = 6;     // PTMI_PLACEMENT_TRIES (round 5: 4 -> 6 — the sets now differ, the losers staying allocated during the search: best of 8 ran 0.7 % ahead of best of 4)
   bool debug_placement = false;
 };
 
@@ -815,7 +815,7 @@ void launch_shade(ptmi_ctx* c, uint32_t sgrid, const RenderConst& rc, const Path
 }
 
 // Placement search (DESIGN.md §3 "placement"): where the driver puts the queue arrays decides how often their streams meet in the same HBM channels — k_shade runs up to 12 %
-// slower in some contexts than in others, for their whole life.  For batches worth the trouble the context therefore tries up to PTMI_PLACEMENT_TRIES (4) sets of queue
+// slower in some contexts than in others, for their whole life.  For batches worth the trouble the context therefore tries up to PTMI_PLACEMENT_TRIES (6) sets of queue
 // arrays, two alive at a time, and keeps the fastest.  Round 5: what is timed on each set is THE BATCH ITSELF — its k_generate and its first two steps, run dry (`dry` =
 // render_batch(..., dry_steps = 2): no accumulation, no counters, no statistics; the real run that follows starts from scratch anyway) — instead of a synthetic kernel that
 // imitated a step's access pattern and predicted the kernels' times poorly (profiles/r05_placement_tries.txt).  The first dry run of a set pages it in and is not counted.
@@ -861,7 +861,25 @@ int placement_search(ptmi_ctx* c, const std::function<int()>& dry) {
   DBuf* mine[10] = {&c->d_q0[0], &c->d_q0[1], &c->d_q1[0], &c->d_q1[1], &c->d_q2[0], &c->d_q2[1], &c->d_tp[0], &c->d_tp[1], &c->d_hm[0], &c->d_hm[1]};
   const size_t width[10] = {16, 16, 16, 16, 16, 16, 8, 8, 4, 4};
   int rc_out = PTMI_OK;
+  // The sets that lost stay allocated until the search is over (while the board has room for them): a set that is freed at once hands its pages to the next
+  // candidate, which then scores the same to the microsecond.
+  struct Losers {
+    std::vector<DBuf> bufs;
+    void drop() {
+      for (DBuf& b : bufs) b.release();
+      bufs.clear();
+    }
+    ~Losers() { drop(); }
+  } losers;
+  size_t set_bytes = 0;
+  for (int k = 0; k < 10; k++) set_bytes += slots * width[k];
   for (int t = 1; t < c->tun.placement_tries; t++) {
+    size_t mem_free = 0, mem_total = 0;
+    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = 0, (void)hipGetLastError();
+    if (mem_free < set_bytes + ((size_t)8 << 30)) {
+      if (losers.bufs.empty()) break;
+      losers.drop();
+    }
     DBuf cand[10];
     bool ok = true;
     for (int k = 0; k < 10 && ok; k++) ok = cand[k].ensure(slots * width[k]) == hipSuccess;  // (an extra allocation that fails just ends the search)
@@ -879,7 +897,14 @@ int placement_search(ptmi_ctx* c, const std::function<int()>& dry) {
       }
     }
     if (!ok) (void)hipStreamSynchronize(c->stream);  // nothing may still run on a set that is about to go
-    for (int k = 0; k < 10; k++) cand[k].release();
+    for (int k = 0; k < 10; k++) {
+      if (ok && cand[k].p) {
+        losers.bufs.emplace_back();
+        std::swap(losers.bufs.back(), cand[k]);
+      } else {
+        cand[k].release();
+      }
+    }
     if (!ok) break;
   }
   restore.stats.placement_sets = sets;
@@ -991,6 +1016,7 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
   if (dry_steps == 0 && c->placement_pending) {
     c->placement_pending = false;
     if (total > tail_limit_first) {  // (a batch that k_tail takes whole reads its queue once: nothing to search for)
+      // (two steps: the whole batch as the probe — eight steps — chose no better: profiles/r05_placement_dry_run.txt)
       int r = placement_search(c, [&]() { return render_batch(c, view16, frame0, n_frames, reset_first, fold, 2); });
       if (r) return r;
     }
