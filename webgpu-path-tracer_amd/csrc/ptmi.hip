@@ -607,15 +607,16 @@ int ensure_paths(ptmi_ctx* c, size_t npaths, int n_ctl, bool need_pixsum) {
     c->path_cap = npaths;
     c->slot_cap = slots;
     c->pixsum_alloc = false;
-    // Batches worth a placement search (placement_search below): >= 16 Mi slots — smaller ones belong to k_tail or last microseconds —, not from ptmi_render_frame,
-    // not where shards share the GPU or the board could not hold two sets.
+    // Batches worth a placement search (placement_search below): >= 16 Mi slots — smaller ones belong to k_tail or last microseconds —, sets of at most 96 GB (round 5: 32 ->
+    // 96, i.e. configs[2]'s 256-frame batches too: k_shade 32.2 ms per step instead of 33.5-34.8 on them), not from ptmi_render_frame, not where shards share the GPU or the
+    // board could not hold two sets.
     const int tries = c->tun.placement_tries;
     c->stats.placement_sets = 0;
     c->stats.placement_ms = 0.0;
     size_t mem_free = 0, mem_total = 0;
     if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = 0, (void)hipGetLastError();
     // (the search itself runs in render_batch, on the batch that asked for these buffers: placement_search)
-    c->placement_pending = tries > 1 && !c->interactive && !c->shares_device && slots >= ((size_t)1 << 24) && slots * 120 <= ((size_t)32 << 30) && mem_free >= slots * 120 * 2;
+    c->placement_pending = tries > 1 && !c->interactive && !c->shares_device && slots >= ((size_t)1 << 24) && slots * 120 <= ((size_t)96 << 30) && mem_free >= slots * 120 * 2;
   }
   if (need_pixsum && !c->pixsum_alloc) {
     HIP_TRY(c, c->d_pixsum.ensure(c->path_cap * 16));
@@ -1050,7 +1051,9 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
       }
     }
     Paths P = paths_of(c, s, rc.num_samples > 1);
-    if (const uint32_t tail_limit = s == 0 ? tail_limit_first : tail_limit_later) {
+    // (dry runs: k_generate and k_shade only — the kernels whose time depends on where the queue arrays lie; k_bvh reads them sparsely, and on a deep tree it would
+    // be nine tenths of the search's time.  Rays that entered the root box are then shaded with what part 1 of hitScene found: other paths, the same access pattern.)
+    if (const uint32_t tail_limit = dry_steps > 0 ? 0u : (s == 0 ? tail_limit_first : tail_limit_later)) {
       int lr = launch_tail(c, rc, P, ctl + s, s == 0 ? 1 : 0, tail_limit, carry_of(s));
       if (lr) return lr;
       // step 0's queue is the whole batch (k_generate fills one slot per path): if that fits the limit k_tail has just been handed all of it —
@@ -1060,7 +1063,7 @@ int render_batch(ptmi_ctx* c, const float* view16, uint32_t frame0, int n_frames
         break;
       }
     }
-    {
+    if (dry_steps == 0) {
       Carry cy = carry_of(s);
       if (!carry || s >= n_steps - c->tun.bvh_carry_last) cy.resv_next = 0u;
       int lr = launch_intersect(c, P, ctl + s, bound, false, s == 0 ? &rc : nullptr, cy);
