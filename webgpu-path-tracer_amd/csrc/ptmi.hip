@@ -607,16 +607,16 @@ int ensure_paths(ptmi_ctx* c, size_t npaths, int n_ctl, bool need_pixsum) {
     c->path_cap = npaths;
     c->slot_cap = slots;
     c->pixsum_alloc = false;
-    // Batches worth a placement search (placement_search below): >= 16 Mi slots — smaller ones belong to k_tail or last microseconds —, sets of at most 96 GB (round 5: 32 ->
-    // 96, i.e. configs[2]'s 256-frame batches too: k_shade 32.2 ms per step instead of 33.5-34.8 on them), not from ptmi_render_frame, not where shards share the GPU or the
-    // board could not hold two sets.
+    // Batches worth a placement search (placement_search below): >= 16 Mi slots — smaller ones belong to k_tail or last microseconds —, sets of at most 32 GB (configs[2]'s
+    // 256-frame batches — 72 GB per set — would gain too, k_shade 32.2 ms per step instead of 33.5-34.8, but allocating five more such sets takes the runtime 10 s:
+    // profiles/r05_placement_dry_run.txt), not from ptmi_render_frame, not where shards share the GPU or the board could not hold two sets.
     const int tries = c->tun.placement_tries;
     c->stats.placement_sets = 0;
     c->stats.placement_ms = 0.0;
     size_t mem_free = 0, mem_total = 0;
     if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = 0, (void)hipGetLastError();
     // (the search itself runs in render_batch, on the batch that asked for these buffers: placement_search)
-    c->placement_pending = tries > 1 && !c->interactive && !c->shares_device && slots >= ((size_t)1 << 24) && slots * 120 <= ((size_t)96 << 30) && mem_free >= slots * 120 * 2;
+    c->placement_pending = tries > 1 && !c->interactive && !c->shares_device && slots >= ((size_t)1 << 24) && slots * 120 <= ((size_t)32 << 30) && mem_free >= slots * 120 * 2;
   }
   if (need_pixsum && !c->pixsum_alloc) {
     HIP_TRY(c, c->d_pixsum.ensure(c->path_cap * 16));
