@@ -61,8 +61,8 @@ typedef struct ptmi_params {
   int32_t stack_size;          /* STACK_SIZE = 20 (traversal aborts when the stack fills, Q7) */
   float background[3];         /* (0,1,1)                                                     */
   float fov_degrees;           /* 60                                                          */
-  int32_t frames_in_flight;    /* ptmi_render batches this many frames per wavefront pass; 0 = auto: a 2^29-path budget
-                                * (256 frames at 1080p, ~80 GB of path state; PTMI_PATH_BUDGET_LOG2 overrides) */
+  int32_t frames_in_flight;    /* ptmi_render batches this many frames per wavefront pass; 0 = auto: a 2^30-path budget
+                                * (512 frames at 1080p, ~160 GB of path state, halved while it does not fit; PTMI_PATH_BUDGET_LOG2 overrides) */
   float tmin;                  /* ray_tmin = 0.000001 (header.wgsl:37): lower end of every t interval and the triangle test's epsilon;
                                 * >= 0 and finite                                             */
   float light_mix;             /* 0.2: probability of following the light sample and its weight in the mixture pdf, the surface

@@ -135,7 +135,7 @@ struct Tuning {
   int shade_blocks_per_cu = 0; // PTMI_SHADE_BLOCKS_PER_CU (0 = from the variant's occupancy)
   int tail_limit = -1;         // PTMI_TAIL_LIMIT: k_tail takes queues of at most this many slots (-1 = kTailLimitFirst / kTailLimitLater, 0 = never)
   bool render_ahead = true;    // PTMI_RENDER_AHEAD=0
-  int path_budget_log2 = 29;   // PTMI_PATH_BUDGET_LOG2: paths per wavefront pass with frames_in_flight = auto
+  int path_budget_log2 = 30;   // PTMI_PATH_BUDGET_LOG2: paths per wavefront pass with frames_in_flight = auto (round 5: 29 -> 30)
   int placement_tries = 6;     // PTMI_PLACEMENT_TRIES (round 5: 4 -> 6 — the sets now differ, the losers staying allocated during the search: best of 8 ran 0.7 % ahead of best of 4)
   bool debug_placement = false;
 };
@@ -1908,10 +1908,11 @@ static int render_one(ptmi_ctx* c, const float* view16, uint32_t first_frame, ui
   if (r) return r;
   // pixels this context owns; a rank that renders 1/N of the image keeps N times more frames in flight
   const size_t npix = std::max<size_t>(1, count_local((uint32_t)c->W * (uint32_t)c->H, c->rank, c->world, c->tile));
-  // auto: as many frames per wavefront pass as a 512 M-path budget allows (256 at 1080p, 64 at 4K; ~160 B of state per path
-  // = 80 of the 288 GB).  Every k_bvh launch ends with a tail as long as its longest ray (~2 ms per step on an 871 k-triangle
-  // tree, whatever the batch size: configs[2] gains 13 % from 64 -> 128 frames), and the sparse Russian-roulette steps and
-  // the launches are amortised over more rays too.  PTMI_PATH_BUDGET_LOG2 overrides (tests, smaller boards).
+  // auto: as many frames per wavefront pass as a 2^30-path budget allows (512 at 1080p, 128 at 4K; ~160 B of state per path
+  // = 160 of the 288 GB; a board — or what is left of one — that cannot hold that gets half, and half again: render_one below).  Every k_bvh launch ends with a
+  // tail as long as its longest ray (~2 ms per step on an 871 k-triangle tree, whatever the batch size: configs[2] gains 13 % from 64 -> 128 frames), and the
+  // sparse Russian-roulette steps and the launches are amortised over more rays too.  Round 5: 2^29 -> 2^30 — 4K at 128 spp +2.5 %, 512 spp of the 871 k-triangle
+  // scene +4 %, of the 262 k interior +0.4 % (profiles/r05_path_budget_ab.txt; 2^27 loses 2-8 %).  PTMI_PATH_BUDGET_LOG2 overrides (tests, smaller boards).
   const int budget_log2 = c->tun.path_budget_log2;
   uint32_t F = c->prm.frames_in_flight > 0 ? (uint32_t)c->prm.frames_in_flight : (uint32_t)std::max<size_t>(1, std::min<size_t>(1024, ((size_t)1 << budget_log2) / npix));
   size_t max_f = std::max<size_t>(1, ((size_t)1 << 31) / npix);  // slot indices (paths + 1/8 + holes) stay below 2^32
