@@ -182,7 +182,7 @@ def make_context(pkg, wl, device, args):
 PMC_PASSES = (
     ("sq", "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_TRANS_F64"),
     ("fetch", "FETCH_SIZE SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32"),
-    ("write", "WRITE_SIZE SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT"),
+    ("write", "WRITE_SIZE SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT TA_TA_BUSY_sum GRBM_GUI_ACTIVE"),  # (TA / GRBM: blocks of their own, they ride along)
 )
 # Issue cost of a wave64 instruction on one SIMD, measured by tools/valu_peak.hip (profiles/valu_peak.json, throughput at 4-8 waves
 # per SIMD): 2 cycles for f32 add/mul/fma (and mov, and/or/xor, integer add), 4 for min/max, compares, shifts, conversions, integer
@@ -300,6 +300,10 @@ def kernel_table(split, steps_in_split, pmc, shade_variant=None):
                 "clock_ghz_in_pmc_pass": ghz,
                 "pmc_pass_avg_launch_ms": p["pmc_ms_sq"] / L,
             })
+        if p and p.get("launches_write") and p.get("GRBM_GUI_ACTIVE") and p.get("TA_TA_BUSY_sum") is not None:
+            # the CU's vector-memory path (texture addresser / L1 <-> registers: a dwordx4 wave instruction occupies it for 64 clocks, 16 bytes per clock and CU):
+            # busy cycles per CU over the kernel's cycles (TA_TA_BUSY is summed over the CUs, GRBM_GUI_ACTIVE over the 8 XCDs)
+            e["ta_busy_frac"] = (p["TA_TA_BUSY_sum"] / (N_SIMD / 4.0)) / (p["GRBM_GUI_ACTIVE"] / 8.0)
         if p and p.get("launches_fetch") and p.get("launches_write"):
             fb = p["FETCH_SIZE"] * 1024.0 / p["launches_fetch"]         # counter unit: KB
             wb = p["WRITE_SIZE"] * 1024.0 / p["launches_write"]
@@ -337,8 +341,20 @@ def roofline_of(tab, dom, timed_ms_per_launch, timed_launches, gather_records_pe
     scale = (e["avg_launch_ms"] / timed_ms_per_launch) if (timed_ms_per_launch and e["avg_launch_ms"]) else 1.0
     vf = vf * scale if vf is not None else None
     hf = hf * scale if hf is not None else None
-    best = max((x for x in (vf, hf, gf) if x is not None))
-    if gf is not None and gf == best:
+    tf = e.get("ta_busy_frac") if dom != "k_bvh" else None  # (k_bvh's reading of the same path is the record model below: exact counters against the probe's rate)
+    if tf is not None:
+        tf = (tf * e["clock_ghz_in_pmc_pass"] / GUIDE_MAX_CLOCK_GHZ if e.get("clock_ghz_in_pmc_pass") else tf) * scale  # against the guide's clock and the timed launch, like the VALU fraction
+    best = max((x for x in (vf, hf, gf, tf) if x is not None))
+    if tf is not None and tf == best:
+        cus = N_SIMD / 4.0
+        r.update({"bound": "vector_memory_path", "achieved": tf * cus * GUIDE_MAX_CLOCK_GHZ * 16.0, "peak": cus * GUIDE_MAX_CLOCK_GHZ * 16.0, "unit": "GB/s", "frac": tf,
+                  "frac_is": "TA_TA_BUSY per CU / the kernel's cycles, re-based on the guide's 2.4 GHz: how busy the CU's vector-memory path (texture addresser / L1 <-> registers) is. "
+                             "A dwordx4 wave instruction occupies it for 64 clocks — 16 bytes per clock and CU, 9.8 TB/s over 256 CUs at 2.4 GHz (tools/gather_probe2.hip: "
+                             "65 clocks per contiguous dwordx4 wave load) — and the 120 bytes of path state a ray brings and takes cross it once each per bounce.  `achieved` = frac x "
+                             "that rate (a busy fraction in bytes' clothing: partial-lane and gather instructions occupy the path for more clocks than their bytes).  The busiest "
+                             "of this kernel's resources; next to it the VALU-issue fraction by the cost model and the fabric bytes",
+                  "peak_definition": "256 CUs x 16 B per clock x 2.4 GHz"})
+    elif gf is not None and gf == best:
         gbs = gather_records_per_launch * 64.0 / (timed_ms_per_launch * 1e-3) / 1e9
         r.update({"bound": "l1_gather", "achieved": gbs, "peak": gpeak * 64.0 / 1e9, "unit": "GB/s", "frac": min(1.0, gf), "frac_unclamped": gf,
                   "peak_definition": "64-byte BVH / triangle records fetched per lane (pair fetches = reference node visits below the root / 2, plus triangle tests; exact counters) "
@@ -361,7 +377,7 @@ def roofline_of(tab, dom, timed_ms_per_launch, timed_launches, gather_records_pe
                              "all-unclassified-at-4 upper bound, rocprof's own VALUBusy (counts every instruction as >= 4 cycles: a kernel of 2-cycle instructions reads "
                              "2x too busy, profiles/r04_valu_busy_calib.json) and the lane-weighted fraction",
                   "peak_definition": "1024 SIMDs x 2.4 GHz / (average issue cycles per wave64 instruction of this kernel = %.2f)" % (e.get("avg_cycles_per_valu_instr") or 0.0)})
-    if r.get("bound") == "valu_issue" and r.get("kernel") == "k_shade":
+    if r.get("bound") in ("valu_issue", "vector_memory_path") and r.get("kernel") == "k_shade":
         r["bound_probes"] = ("round 5 (profiles/NOTES_r05.md §3): a quarter of this kernel's vector instructions removed three bit-exact ways (direction-binned flush passes, "
                              "hit_quad for axis-aligned quads, a quad's Lambertian frame from a table) changes its time by 0 +- 2 %; 16 more bytes per kept ray (+12 % traffic) cost "
                              "6-8 %; most of its traffic removed (paths kept in their lanes) with a fifth more instructions costs 7 %.  `frac` is the busiest resource, not a "
@@ -369,6 +385,9 @@ def roofline_of(tab, dom, timed_ms_per_launch, timed_launches, gather_records_pe
     if max(vf or 0.0, hf or 0.0, gf or 0.0) < 0.5:
         r["bound_note"] = "no resource is busy half the time: the kernel waits on memory latency (wave_wait_frac %.2f)" % (e.get("wave_wait_frac") or 0.0)
     r["valu_busy_frac_at_2p4_ghz"], r["fabric_frac_of_hbm_peak"], r["l1_gather_frac"] = vf, hf, gf
+    if e.get("ta_busy_frac") is not None:
+        r["ta_busy_frac"] = e["ta_busy_frac"]
+        r["ta_busy_frac_is"] = "TA_TA_BUSY per CU / the kernel's cycles: how busy the CU's vector-memory path (L1 <-> registers, 16 bytes per clock and CU) is with this kernel's loads and stores"
     for k in ("valu_busy_frac_at_pass_clock", "valu_busy_frac_upper_bound_at_pass_clock", "rocprof_valu_busy", "rocprof_valu_utilization", "lane_weighted_frac_at_2p4_ghz",
               "clock_ghz_in_pmc_pass", "cost_model"):
         if e.get(k) is not None:

@@ -69,7 +69,7 @@ def test_bench_line_contract_with_its_own_pmc_passes():
     assert roof["kernel"] == max(tab, key=lambda k: tab[k]["ms_per_step"])
     if "pmc_note" not in roof:  # rocprofv3 is on the GPU box: the passes must have produced the fractions
         # fractions are NOT clamped any more: a model that passes 1 must show it; on this small batch they stay well below 1.25
-        assert roof["bound"] in ("valu_issue", "hbm", "l1_gather") and 0 < roof["frac"] < 1.25
+        assert roof["bound"] in ("valu_issue", "hbm", "l1_gather", "vector_memory_path") and 0 < roof["frac"] < 1.25
         assert roof["traffic"] > 0 and "rocprofv3 --pmc passes made by this run" in roof["pmc_source"]
         assert "valu_busy_frac_at_2p4_ghz" in tab[roof["kernel"]]
         for k in ("step_fabric_bytes", "compulsory_bytes", "state_traffic_bytes"):

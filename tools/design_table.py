@@ -27,10 +27,10 @@ spp = {"c2": "64 spp", "c3": "256 spp", "c4": "512 spp", "c5": "128 spp"}
 rows.append("| ms per step | " + " | ".join("%.1f (%s)" % (D[w]["ms_per_step"], spp[w]) for w in cols) + " |")
 rows.append("| node visits / triangle tests per ray | " + " | ".join("%.1f / %.2f" % (D[w]["roofline"]["work_per_ray"]["node_visits"], D[w]["roofline"]["work_per_ray"]["tri_tests"]) for w in cols) + " |")
 rows.append("| ms per step: generate / bvh / shade / tail / accumulate | " + " | ".join(" / ".join(f(k(w, n)["ms_per_step"], 2 if k(w, n)["ms_per_step"] < 100 else 0) for n in ("k_generate", "k_bvh", "k_shade", "k_tail", "k_accumulate")) for w in cols) + " |")
-rows.append("| dominant kernel: bound, `frac` | " + " | ".join("`%s`: %s **%.2f**" % (D[w]["roofline"]["kernel"], {"valu_issue": "VALU issue at 2.4 GHz", "l1_gather": "L1 gather at 2.4 GHz", "hbm": "HBM"}[D[w]["roofline"]["bound"]], D[w]["roofline"]["frac"]) for w in cols) + " |")
+rows.append("| dominant kernel: bound, `frac` | " + " | ".join("`%s`: %s **%.2f**" % (D[w]["roofline"]["kernel"], {"valu_issue": "VALU issue at 2.4 GHz", "l1_gather": "L1 gather at 2.4 GHz", "hbm": "HBM", "vector_memory_path": "vector-memory path (TA busy) at 2.4 GHz"}[D[w]["roofline"]["bound"]], D[w]["roofline"]["frac"]) for w in cols) + " |")
 rows.append("| the same kernel: VALU model at the pass clock / all-unclassified-at-4 upper bound / rocprof VALUBusy / lane-weighted at 2.4 GHz | " + " | ".join("%s / %s / %s / %s" % (f(D[w]["roofline"].get("valu_busy_frac_at_pass_clock")), f(D[w]["roofline"].get("valu_busy_frac_upper_bound_at_pass_clock")), f(D[w]["roofline"].get("rocprof_valu_busy")), f(D[w]["roofline"].get("lane_weighted_frac_at_2p4_ghz"))) for w in cols) + " |")
-rows.append("| `k_bvh`: L1 gather / VALU at 2.4 GHz / fabric bytes ÷ 8 TB/s / active lanes / waves parked on memory | " + " | ".join("%s / %s / %s / %s / %s" % (f(k(w, "k_bvh").get("l1_gather_frac")), f(k(w, "k_bvh").get("valu_busy_frac_at_2p4_ghz")), f(k(w, "k_bvh").get("fabric_frac_of_hbm_peak")), f(k(w, "k_bvh").get("active_lane_frac")), f(k(w, "k_bvh").get("wave_wait_frac"))) for w in cols) + " |")
-rows.append("| `k_shade`: VALU at 2.4 GHz / rocprof VALUBusy / fabric bytes ÷ 8 TB/s / active lanes / waves parked | " + " | ".join("%s / %s / %s / %s / %s" % (f(k(w, "k_shade").get("valu_busy_frac_at_2p4_ghz")), f(k(w, "k_shade").get("rocprof_valu_busy")), f(k(w, "k_shade").get("fabric_frac_of_hbm_peak")), f(k(w, "k_shade").get("active_lane_frac")), f(k(w, "k_shade").get("wave_wait_frac"))) for w in cols) + " |")
+rows.append("| `k_bvh`: L1 gather / TA busy (pass clock) / VALU at 2.4 GHz / fabric bytes ÷ 8 TB/s / active lanes / waves parked on memory | " + " | ".join("%s / %s / %s / %s / %s / %s" % (f(k(w, "k_bvh").get("l1_gather_frac")), f(k(w, "k_bvh").get("ta_busy_frac")), f(k(w, "k_bvh").get("valu_busy_frac_at_2p4_ghz")), f(k(w, "k_bvh").get("fabric_frac_of_hbm_peak")), f(k(w, "k_bvh").get("active_lane_frac")), f(k(w, "k_bvh").get("wave_wait_frac"))) for w in cols) + " |")
+rows.append("| `k_shade`: TA busy (pass clock) / VALU at 2.4 GHz / rocprof VALUBusy / fabric bytes ÷ 8 TB/s / active lanes / waves parked | " + " | ".join("%s / %s / %s / %s / %s / %s" % (f(k(w, "k_shade").get("ta_busy_frac")), f(k(w, "k_shade").get("valu_busy_frac_at_2p4_ghz")), f(k(w, "k_shade").get("rocprof_valu_busy")), f(k(w, "k_shade").get("fabric_frac_of_hbm_peak")), f(k(w, "k_shade").get("active_lane_frac")), f(k(w, "k_shade").get("wave_wait_frac"))) for w in cols) + " |")
 rows.append("| `k_generate`: VALU at 2.4 GHz / at the pass clock / rocprof VALUBusy / fabric bytes ÷ 8 TB/s | " + " | ".join("%s / %s / %s / %s" % (f(k(w, "k_generate").get("valu_busy_frac_at_2p4_ghz")), f(k(w, "k_generate").get("valu_busy_frac_at_pass_clock")), f(k(w, "k_generate").get("rocprof_valu_busy")), f(k(w, "k_generate").get("fabric_frac_of_hbm_peak"))) for w in cols) + " |")
 rows.append("| one step over the fabric: GB / ÷ 8 TB/s / × the reference megakernel's compulsory bytes | " + " | ".join("%.1f / %s / %.1f×" % (D[w]["roofline"]["step_fabric_bytes"] / 1e9, f(D[w]["roofline"].get("step_fabric_frac_of_hbm_peak")), D[w]["roofline"]["step_fabric_bytes"] / D[w]["roofline"]["compulsory_bytes"]) if D[w]["roofline"].get("step_fabric_bytes") else "—" for w in cols) + " |")
 S = {}
